@@ -1,0 +1,121 @@
+/* peaksegdisk_hip.h -- C ABI of libpeaksegdisk_hip.so, the MI355X-native drop-in for
+ * PeakSegDisk's PeakSegFPOP hot path.
+ *
+ * Plain C types only (pointers, sizes, ints, doubles).  Each entry point cites the
+ * reference interface it replaces; INTEGRATION.md shows the bindings (R `.C` glue, ctypes).
+ */
+#ifndef PEAKSEGDISK_HIP_H
+#define PEAKSEGDISK_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------- */
+/* 1..11: identical to /root/reference/src/PeakSegFPOPLog.h:3-13 */
+#define ERROR_PENALTY_NOT_FINITE 1
+#define ERROR_PENALTY_NEGATIVE 2
+#define ERROR_UNABLE_TO_OPEN_BEDGRAPH 3
+#define ERROR_NOT_ENOUGH_COLUMNS 4
+#define ERROR_NON_INTEGER_DATA 5
+#define ERROR_INCONSISTENT_CHROMSTART_CHROMEND 6
+#define ERROR_WRITING_COST_FUNCTIONS 7
+#define ERROR_WRITING_LOSS_OUTPUT 8
+#define ERROR_NO_DATA 9
+#define ERROR_PENALTY_NOT_NUMERIC 10
+#define ERROR_WRITING_SEGMENTS_OUTPUT 11
+/* additions of this implementation (the reference reports "error code %d" for them) */
+#define ERROR_NO_HIP_DEVICE 12     /* no MI355X visible: there is no CPU fallback */
+#define ERROR_DEVICE_SOLVER 13     /* kernel reported a failure; see peakseg_hip_last_error() */
+#define ERROR_DEVICE_MEMORY 14     /* arena / tables do not fit in HBM */
+
+/* ---- the reference's boundary -------------------------------------------------------- */
+
+/* Replaces `int PeakSegFPOP_disk(char*, char*, char*)`
+ * (/root/reference/src/PeakSegFPOPLog.h:15, PeakSegFPOPLog.cpp:143-463): same arguments,
+ * same status codes, same validation order, byte-identical
+ * <bedGraph>_penalty=<pen>_segments.bed / _loss.tsv files.  The dynamic program runs on the
+ * GPU and the cost-function store lives in HBM; db_file_name is still opened (status 7 if
+ * that fails, as the reference) and is left as a sparse file of exactly the size the
+ * reference's database would have, so callers that report its size keep working. */
+int PeakSegFPOP_disk(char *bedGraph_file_name, char *penalty_str, char *db_file_name);
+
+/* Additive batch form of the same call for penalty grids: problem i is
+ * (bedGraph_files[i], penalty_strs[i], db_files[i]); every distinct bedGraph file is parsed
+ * and uploaded once, all dynamic programs run concurrently (one workgroup each), and the
+ * output files are byte-identical to n separate PeakSegFPOP_disk calls.  status_out[i]
+ * receives each problem's status; the return value is the first non-zero one (0 if none). */
+int PeakSegFPOP_disk_batch(int n_problems, char **bedGraph_files, char **penalty_strs,
+                           char **db_files, int *status_out);
+
+/* The text the reference's glue passes to Rf_error for a status
+ * (/root/reference/src/interface.cpp:16-55); returns buf; empty string for status 0. */
+char *PeakSegFPOP_status_message(int status, const char *bedGraph, const char *penalty,
+                                 const char *db, char *buf, size_t buf_len);
+
+/* Where "problem: %d items on line %d" goes (the reference Rprintf()s it,
+ * PeakSegFPOPLog.cpp:181).  NULL restores the default (stdout). */
+void peakseg_hip_set_print(void (*print)(const char *text));
+
+/* ---- device-resident problem sets (penalty x contig grids, benchmarking) ------------ */
+
+typedef struct psd_problem_set psd_problem_set;
+
+typedef struct {
+  int status;             /* 0, or ERROR_DEVICE_* */
+  int kernel_status;      /* PST_* detail from the kernel */
+  int n_segments;
+  int n_peaks;
+  int n_equality_constraints;
+  int max_intervals;
+  unsigned long long total_intervals;
+  double best_cost;       /* mean penalized cost (loss.tsv column 6) */
+  int n_serial_env;       /* diagnostics: min-envelope calls replayed sequentially */
+  int step_reached;
+} psd_result;
+
+int peakseg_hip_device_count(void);
+const char *peakseg_hip_last_error(void);
+
+/* Upload contigs (count = 4th bedGraph column, weight = chromEnd-chromStart) and the
+ * problem list to HBM and allocate the arena (arena_pieces = 0: sized automatically and
+ * grown on demand).  One problem = one (contig, penalty) dynamic program. */
+int peakseg_hip_problem_set_create(int device, int n_contigs, const int *contig_n_bins,
+                                   const int *const *contig_count,
+                                   const int *const *contig_weight, int n_problems,
+                                   const int *problem_contig, const double *problem_penalty,
+                                   unsigned long long arena_pieces, psd_problem_set **out);
+
+/* Run forward DP + backtrack for every problem of the set; inputs are already resident.
+ * Kernel durations are measured with HIP events on the stream the kernels run on. */
+int peakseg_hip_problem_set_solve(psd_problem_set *set, float *forward_ms, float *backtrack_ms);
+
+int peakseg_hip_problem_set_result(psd_problem_set *set, int problem, psd_result *out);
+
+/* Segment table of one problem in the reference's output order (last segment first):
+ * seg_start[r] = index of the data point whose chromEnd starts segment r (-1: the first
+ * chromStart), seg_mean[r] = segment mean.  Returns the number of rows, or -1. */
+int peakseg_hip_problem_set_segments(psd_problem_set *set, int problem, int capacity,
+                                     int *seg_start, double *seg_mean);
+
+/* Debug/parity aid: write one problem's in-HBM cost-function store in the byte layout of
+ * the reference's DiskVector file (PeakSegFPOPLog.cpp:12-34,76-141); chromEnd[] supplies
+ * the per-function chromEnd field. */
+int peakseg_hip_problem_set_export_db(psd_problem_set *set, int problem, const int *chromEnd,
+                                      const char *path);
+
+/* bytes of HBM held by the set (arena + tables) */
+unsigned long long peakseg_hip_problem_set_bytes(psd_problem_set *set);
+
+void peakseg_hip_problem_set_destroy(psd_problem_set *set);
+
+/* y[i] = exp(x[i]) (op 0) or log(x[i]) (op 1) evaluated on the device with the library's
+ * deterministic math (include/peakseg_detmath.h); tests compare with the host build. */
+int peakseg_hip_math_probe(int op, int n, const double *x, double *y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,102 @@
+"""ctypes binding of libpeaksegdisk_hip.so (the C ABI declared in include/peaksegdisk_hip.h).
+
+The library is the only solver: importing this module fails loudly when it has not been
+built (`python -c "import __graft_entry__ as g; g.build()"`), and every dynamic program
+fails with ERROR_NO_HIP_DEVICE when no MI355X is visible.  There is no CPU fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpeaksegdisk_hip.so")
+
+ERROR_NO_HIP_DEVICE = 12
+ERROR_DEVICE_SOLVER = 13
+ERROR_DEVICE_MEMORY = 14
+
+
+class PsdResult(ctypes.Structure):
+    _fields_ = [
+        ("status", ctypes.c_int),
+        ("kernel_status", ctypes.c_int),
+        ("n_segments", ctypes.c_int),
+        ("n_peaks", ctypes.c_int),
+        ("n_equality_constraints", ctypes.c_int),
+        ("max_intervals", ctypes.c_int),
+        ("total_intervals", ctypes.c_ulonglong),
+        ("best_cost", ctypes.c_double),
+        ("n_serial_env", ctypes.c_int),
+        ("step_reached", ctypes.c_int),
+    ]
+
+
+def declare(lib):
+    """Attach argtypes/restypes for every symbol of include/peaksegdisk_hip.h."""
+    c = ctypes
+    lib.PeakSegFPOP_disk.argtypes = [c.c_char_p, c.c_char_p, c.c_char_p]
+    lib.PeakSegFPOP_disk.restype = c.c_int
+    lib.PeakSegFPOP_disk_batch.argtypes = [
+        c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_char_p), c.POINTER(c.c_char_p),
+        c.POINTER(c.c_int)]
+    lib.PeakSegFPOP_disk_batch.restype = c.c_int
+    lib.PeakSegFPOP_status_message.argtypes = [
+        c.c_int, c.c_char_p, c.c_char_p, c.c_char_p, c.c_char_p, c.c_size_t]
+    lib.PeakSegFPOP_status_message.restype = c.c_char_p
+    lib.peakseg_hip_set_print.argtypes = [c.c_void_p]
+    lib.peakseg_hip_set_print.restype = None
+    lib.peakseg_hip_device_count.argtypes = []
+    lib.peakseg_hip_device_count.restype = c.c_int
+    lib.peakseg_hip_last_error.argtypes = []
+    lib.peakseg_hip_last_error.restype = c.c_char_p
+    lib.peakseg_hip_problem_set_create.argtypes = [
+        c.c_int, c.c_int, c.POINTER(c.c_int), c.POINTER(c.c_void_p), c.POINTER(c.c_void_p),
+        c.c_int, c.POINTER(c.c_int), c.POINTER(c.c_double), c.c_ulonglong,
+        c.POINTER(c.c_void_p)]
+    lib.peakseg_hip_problem_set_create.restype = c.c_int
+    lib.peakseg_hip_problem_set_solve.argtypes = [
+        c.c_void_p, c.POINTER(c.c_float), c.POINTER(c.c_float)]
+    lib.peakseg_hip_problem_set_solve.restype = c.c_int
+    lib.peakseg_hip_problem_set_result.argtypes = [c.c_void_p, c.c_int, c.POINTER(PsdResult)]
+    lib.peakseg_hip_problem_set_result.restype = c.c_int
+    lib.peakseg_hip_problem_set_segments.argtypes = [
+        c.c_void_p, c.c_int, c.c_int, c.c_void_p, c.c_void_p]
+    lib.peakseg_hip_problem_set_segments.restype = c.c_int
+    lib.peakseg_hip_problem_set_export_db.argtypes = [
+        c.c_void_p, c.c_int, c.c_void_p, c.c_char_p]
+    lib.peakseg_hip_problem_set_export_db.restype = c.c_int
+    lib.peakseg_hip_problem_set_bytes.argtypes = [c.c_void_p]
+    lib.peakseg_hip_problem_set_bytes.restype = c.c_ulonglong
+    lib.peakseg_hip_problem_set_destroy.argtypes = [c.c_void_p]
+    lib.peakseg_hip_problem_set_destroy.restype = None
+    lib.peakseg_hip_math_probe.argtypes = [c.c_int, c.c_int, c.c_void_p, c.c_void_p]
+    lib.peakseg_hip_math_probe.restype = c.c_int
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "PeakSegFPOP_disk", "PeakSegFPOP_disk_batch", "PeakSegFPOP_status_message",
+    "peakseg_hip_set_print", "peakseg_hip_device_count", "peakseg_hip_last_error",
+    "peakseg_hip_problem_set_create", "peakseg_hip_problem_set_solve",
+    "peakseg_hip_problem_set_result", "peakseg_hip_problem_set_segments",
+    "peakseg_hip_problem_set_export_db", "peakseg_hip_problem_set_bytes",
+    "peakseg_hip_problem_set_destroy", "peakseg_hip_math_probe",
+]
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "%s is missing: build the HIP extension first "
+        "(python -c 'import __graft_entry__ as g; g.build()'). "
+        "peaksegdisk_amd has no CPU fallback." % LIB_PATH)
+
+lib = declare(ctypes.CDLL(LIB_PATH))
+
+
+def last_error():
+    return lib.peakseg_hip_last_error().decode(errors="replace")
+
+
+def status_message(status, bedgraph, penalty, db):
+    buf = ctypes.create_string_buffer(4096)
+    lib.PeakSegFPOP_status_message(
+        status, os.fsencode(bedgraph), penalty.encode(), os.fsencode(db), buf, len(buf))
+    return buf.value.decode(errors="replace")

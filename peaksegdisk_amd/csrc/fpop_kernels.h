@@ -1,0 +1,466 @@
+/* fpop_kernels.h -- the HIP kernels of the PeakSegFPOP hot path.
+ *
+ *   fpop_forward_kernel   one workgroup of two wavefronts per (penalty, contig) problem:
+ *                         wave 0 carries the "up" cost function, wave 1 the "down" one, through
+ *                         the strictly sequential recurrence of
+ *                         /root/reference/src/PeakSegFPOPLog.cpp:258-397 (one __syncthreads
+ *                         per data point; the two updates of a step only read the previous
+ *                         step's functions).  Live piece lists sit in LDS; each step's
+ *                         backtrack record {max_log_mean, data_i, prev_log_mean} per piece --
+ *                         what the reference serialises to its DiskVector (drv:12-34) -- is
+ *                         appended to the in-HBM arena.
+ *   fpop_backtrack_kernel one wavefront per problem decodes the segmentation from the arena
+ *                         (drv:399-442: Minimize result, then findMean per segment).
+ *   math_probe_kernel     element-wise psd_exp / psd_log (tests: host == device bit for bit).
+ *
+ * Included by peakseg_hip.cpp (hipcc, gfx950) and by tests/emu (g++ + hip_emu.h).
+ */
+#ifndef PSD_FPOP_KERNELS_H
+#define PSD_FPOP_KERNELS_H
+
+#include "fpop_wave.h"
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+namespace psd {
+
+constexpr int LDS_CAP = 128;          /* pieces per LDS-resident list */
+constexpr int ARENA_CHUNK_LOG2 = 16;  /* arena is handed out in chunks of 65536 pieces */
+constexpr int ARENA_CHUNK = 1 << ARENA_CHUNK_LOG2;
+constexpr int FN_COUNT_BITS = 24;     /* fn_ref = (arena offset << 24) | piece count */
+
+/* problem status written by the kernels (0 = ok) */
+enum {
+  PST_OK = 0,
+  PST_LDS_OVERFLOW = 1,  /* a list outgrew LDS_CAP and the spill path is not available */
+  PST_ARENA_FULL = 2,    /* host retries with a larger arena */
+  PST_REF_THROW = 3,     /* the reference would throw / loop / read a list sentinel */
+  PST_BACKTRACK = 4,     /* findMean found no piece (the reference would never return) */
+};
+
+struct ProbResult {
+  double best_cost;       /* Minimize() of the last down function (drv:404-406) */
+  double best_log_mean;
+  double prev_log_mean;
+  int prev_seg_end;
+  int status;
+  int wave_err;           /* WERR_* bits for diagnostics */
+  int max_intervals;      /* drv:374-379 */
+  unsigned long long total_intervals; /* drv:373 */
+  int n_segments;         /* filled by the backtrack kernel */
+  int n_equality;         /* drv:411,436 */
+  int n_serial_env;       /* min-envelope calls that needed the sequential replay */
+  int step_reached;
+};
+
+struct DeviceArgs {
+  int n_problems;
+  /* per problem */
+  const int *prob_contig;
+  const double *prob_penalty;
+  const long long *prob_fn_off;  /* into fn_ref: 2*N entries (up: [0,N), down: [N,2N)) */
+  const long long *prob_seg_off; /* into seg_start / seg_mean: N+1 entries */
+  ProbResult *result;
+  /* per contig */
+  const int *contig_n;
+  const long long *contig_off; /* into count / weight */
+  const double *contig_min_log_mean;
+  const double *contig_max_log_mean;
+  const int *count;  /* 4th bedGraph column */
+  const int *weight; /* chromEnd - chromStart */
+  /* arena: the in-HBM cost-function store */
+  double *ar_mx;
+  double *ar_prv;
+  int *ar_di;
+  unsigned long long ar_cap; /* pieces */
+  unsigned long long *ar_next_chunk;
+  unsigned long long *fn_ref;
+  /* segment tables, in backtrack order */
+  int *seg_start;   /* data index whose chromEnd starts the segment; -1 = first_chromStart */
+  double *seg_mean; /* exp(best_log_mean) */
+};
+
+struct ListStore {
+  double Lin[LDS_CAP], Log[LDS_CAP], Con[LDS_CAP], mn[LDS_CAP], mx[LDS_CAP], prv[LDS_CAP];
+  int di[LDS_CAP];
+};
+struct ScratchStore {
+  double lc[LDS_CAP], rc[LDS_CAP], mu[LDS_CAP], muc[LDS_CAP];
+  int cls[LDS_CAP];
+  int iv[2 * LDS_CAP];
+};
+struct SharedBlock {
+  ListStore up[2], down[2], m[2];
+  ScratchStore sc[2];
+  int n_up[2], n_down[2];
+  int abort_status;
+  int abort_err;
+  unsigned long long total_up;
+  int max_up;
+  int serial_up;
+};
+
+PSD_D ListView view_of(ListStore &s) {
+  ListView v;
+  v.Lin = s.Lin;
+  v.Log = s.Log;
+  v.Con = s.Con;
+  v.mn = s.mn;
+  v.mx = s.mx;
+  v.prv = s.prv;
+  v.di = s.di;
+  return v;
+}
+PSD_D WaveScratch scratch_of(ScratchStore &s) {
+  WaveScratch w;
+  w.lc = s.lc;
+  w.rc = s.rc;
+  w.mu = s.mu;
+  w.muc = s.muc;
+  w.cls = s.cls;
+  w.iv = s.iv;
+  return w;
+}
+
+/* f <- (f * cum_weight_prev + (weight, -coverage*weight, 0)) * (1/cum_weight)
+ * exactly as drv:316-321 / 365-370: multiply, add, multiply, no contraction. */
+PSD_D void scale_add_wave(const ListView &f, int n, double cum_weight_prev, double add_linear,
+                          double add_log, double inv_cum_weight) {
+  const int lane = lane_id();
+  for (int base = 0; base < n; base += WAVE) {
+    int i = base + lane;
+    if (i < n) {
+      double li = f.Lin[i] * cum_weight_prev;
+      double lo = f.Log[i] * cum_weight_prev;
+      double co = f.Con[i] * cum_weight_prev;
+      li = li + add_linear;
+      lo = lo + add_log;
+      co = co + 0.0;
+      f.Lin[i] = li * inv_cum_weight;
+      f.Log[i] = lo * inv_cum_weight;
+      f.Con[i] = co * inv_cum_weight;
+    }
+  }
+}
+
+struct ArenaCursor {
+  unsigned long long base; /* first piece of the current chunk run */
+  int used, room;
+};
+
+/* Append one function's backtrack record to the arena; returns false when it is full. */
+PSD_D bool arena_store_wave(const DeviceArgs &a, ArenaCursor &cur, const ListView &f, int n,
+                            unsigned long long fn_index) {
+  const int lane = lane_id();
+  if (n > cur.room - cur.used) {
+    int chunks = (n + ARENA_CHUNK - 1) >> ARENA_CHUNK_LOG2;
+    unsigned long long first = 0;
+    if (lane == 0) first = atomicAdd(a.ar_next_chunk, (unsigned long long)chunks);
+    first = psd_d2u(shfl_d(psd_u2d(first), 0));
+    cur.base = first << ARENA_CHUNK_LOG2;
+    cur.used = 0;
+    cur.room = chunks << ARENA_CHUNK_LOG2;
+    if (cur.base + (unsigned long long)cur.room > a.ar_cap) return false;
+  }
+  unsigned long long off = cur.base + (unsigned long long)cur.used;
+  for (int base = 0; base < n; base += WAVE) {
+    int i = base + lane;
+    if (i < n) {
+      a.ar_mx[off + i] = f.mx[i];
+      a.ar_prv[off + i] = f.prv[i];
+      a.ar_di[off + i] = f.di[i];
+    }
+  }
+  if (lane == 0) a.fn_ref[fn_index] = (off << FN_COUNT_BITS) | (unsigned long long)n;
+  cur.used += n;
+  return true;
+}
+
+/* Minimize (fpl:689-712): first strict minimum over pieces of the clamped optimum. */
+PSD_D void minimize_wave(const ListView &f, int n, double *best_cost, double *best_log_mean,
+                         int *data_i, double *prev_log_mean) {
+  const int lane = lane_id();
+  double bc = PSD_INF, blm = 0.0, bprv = 0.0;
+  int bdi = 0;
+  for (int base = 0; base < n; base += WAVE) {
+    int i = base + lane;
+    double cost = PSD_INF, lm = 0.0;
+    if (i < n) {
+      Coef c = load_coef(f, i);
+      lm = argmin(c);
+      if (lm < f.mn[i]) {
+        lm = f.mn[i];
+      } else if (f.mx[i] < lm) {
+        lm = f.mx[i];
+      }
+      cost = get_cost(c, lm);
+    }
+    /* lowest lane among those holding the chunk minimum; NaN never wins a strict '<' */
+    bool usable = i < n && cost < PSD_INF;
+    double v = usable ? cost : PSD_INF;
+    double mn = v;
+    for (int sft = 1; sft < WAVE; sft <<= 1) {
+      double o = shfl_d(mn, lane ^ sft);
+      mn = o < mn ? o : mn;
+    }
+    unsigned long long m = ballot(usable && v == mn);
+    if (m && mn < bc) {
+      int src = ctz64(m);
+      bc = mn;
+      blm = shfl_d(lm, src);
+      int ii = base + src;
+      bdi = f.di[ii];
+      bprv = f.prv[ii];
+    }
+  }
+  *best_cost = bc;
+  *best_log_mean = blm;
+  *data_i = bdi;
+  *prev_log_mean = bprv;
+}
+
+__global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
+  __shared__ SharedBlock sm;
+  const int p = (int)blockIdx.x;
+  const int wave = wave_id();
+  const int lane = lane_id();
+  const int contig = a.prob_contig[p];
+  const int N = a.contig_n[contig];
+  const double penalty = a.prob_penalty[p];
+  const int *count = a.count + a.contig_off[contig];
+  const int *weight = a.weight + a.contig_off[contig];
+  const unsigned long long fn0 = (unsigned long long)a.prob_fn_off[p];
+  const WaveScratch sc = scratch_of(sm.sc[wave]);
+  const ListView mview = view_of(sm.m[wave]);
+
+  if (threadIdx.x == 0) {
+    sm.abort_status = 0;
+    sm.abort_err = 0;
+    sm.n_up[0] = sm.n_up[1] = 0;
+    sm.n_down[0] = sm.n_down[1] = 0;
+  }
+  __syncthreads();
+
+  ArenaCursor cur;
+  cur.base = 0;
+  cur.used = 0;
+  cur.room = 0;
+  unsigned long long total_intervals = 0;
+  int max_intervals = 0;
+  int n_serial = 0;
+  int err = 0;
+  int status = 0;
+  double cum_weight_i = 0.0, cum_weight_prev_i = -1.0;
+  int cnt_reg = 0, wt_reg = 0;
+  int b = 0; /* sm.up[b], sm.down[b] hold step t-1 */
+  int t = 0;
+  for (; t < N; t++) {
+    if ((t & 63) == 0) { /* coalesced read of the next 64 data points */
+      int tt = t + lane;
+      cnt_reg = tt < N ? count[tt] : 0;
+      wt_reg = tt < N ? weight[tt] : 0;
+    }
+    const int coverage = shfl_i(cnt_reg, t & 63);
+    const double w = (double)shfl_i(wt_reg, t & 63);
+    cum_weight_i += w;
+    const int nb = b ^ 1;
+    int n_new = 0;
+    if (t == 0) {
+      /* C^down_1 = gamma_1 / w_1 (drv:266-270); there is no up function yet */
+      if (wave == 1) {
+        if (lane == 0) {
+          Coef c;
+          c.Linear = 1.0;
+          c.Log = (double)(-coverage);
+          c.Constant = 0.0;
+          store_piece(view_of(sm.down[nb]), 0, c, a.contig_min_log_mean[contig],
+                      a.contig_max_log_mean[contig], -1, -5.0);
+        }
+        n_new = 1;
+      }
+    } else {
+      const double add_linear = w;
+      const double add_log = (double)(-coverage) * w;
+      const double inv_cw = 1 / cum_weight_i;
+      if (wave == 0) { /* up_t (drv:273-321) */
+        const ListView dprev = view_of(sm.down[b]);
+        const ListView unew = view_of(sm.up[nb]);
+        const double pen_term = penalty / cum_weight_prev_i;
+        if (t == 1) {
+          n_new = min_less_wave(dprev, sm.n_down[b], unew, LDS_CAP, sc, t - 1, pen_term, &err);
+        } else {
+          int nm = min_less_wave(dprev, sm.n_down[b], mview, LDS_CAP, sc, t - 1, pen_term, &err);
+          if (!(err & WERR_OVERFLOW))
+            n_new = min_env_wave(mview, nm, view_of(sm.up[b]), sm.n_up[b], unew, LDS_CAP, sc,
+                                 2 * LDS_CAP, &n_serial, &err);
+        }
+        wave_sync();
+        scale_add_wave(unew, n_new, cum_weight_prev_i, add_linear, add_log, inv_cw);
+      } else { /* down_t (drv:324-370) */
+        const ListView dprev = view_of(sm.down[b]);
+        const ListView dnew = view_of(sm.down[nb]);
+        if (t == 1) {
+          n_new = sm.n_down[b];
+          for (int base = 0; base < n_new; base += WAVE) {
+            int i = base + lane;
+            if (i < n_new)
+              store_piece(dnew, i, load_coef(dprev, i), dprev.mn[i], dprev.mx[i], dprev.di[i],
+                          dprev.prv[i]);
+          }
+        } else {
+          int head = 0;
+          int nm = min_more_wave(view_of(sm.up[b]), sm.n_up[b], mview, LDS_CAP, sc, t - 1, &head,
+                                 &err);
+          if (!(err & WERR_OVERFLOW))
+            n_new = min_env_wave(list_offset(mview, head), nm, dprev, sm.n_down[b], dnew, LDS_CAP,
+                                 sc, 2 * LDS_CAP, &n_serial, &err);
+        }
+        wave_sync();
+        scale_add_wave(dnew, n_new, cum_weight_prev_i, add_linear, add_log, inv_cw);
+      }
+    }
+    wave_sync();
+    /* ---- end of step: publish sizes, commit the backtrack record ---- */
+    unsigned long long any_err = ballot(err != 0);
+    if (any_err) {
+      int e = 0;
+      for (int l = 0; l < WAVE; l++) e |= shfl_i(err, l);
+      if (lane == 0) {
+        sm.abort_err = e; /* both waves may write: either value is a valid report */
+        sm.abort_status = (e & WERR_OVERFLOW) ? PST_LDS_OVERFLOW : PST_REF_THROW;
+      }
+    } else if (wave == 0) {
+      if (t > 0) {
+        if (!arena_store_wave(a, cur, view_of(sm.up[nb]), n_new, fn0 + (unsigned long long)t)) {
+          if (lane == 0) sm.abort_status = PST_ARENA_FULL;
+        }
+      }
+      if (lane == 0) sm.n_up[nb] = n_new;
+    } else {
+      if (!arena_store_wave(a, cur, view_of(sm.down[nb]), n_new,
+                            fn0 + (unsigned long long)N + (unsigned long long)t)) {
+        if (lane == 0) sm.abort_status = PST_ARENA_FULL;
+      }
+      if (lane == 0) sm.n_down[nb] = n_new;
+    }
+    total_intervals += (unsigned long long)n_new;
+    if (max_intervals < n_new) max_intervals = n_new;
+    cum_weight_prev_i = cum_weight_i;
+    __syncthreads();
+    status = sm.abort_status;
+    if (status != 0) break;
+    b = nb;
+  }
+  /* ---- after the last data point: Minimize the final down function (drv:404-406) ---- */
+  if (wave == 0 && lane == 0) {
+    sm.total_up = total_intervals;
+    sm.max_up = max_intervals;
+    sm.serial_up = n_serial;
+  }
+  __syncthreads();
+  if (wave == 1) {
+    ProbResult r;
+    r.best_cost = 0.0;
+    r.best_log_mean = 0.0;
+    r.prev_log_mean = 0.0;
+    r.prev_seg_end = -1;
+    r.status = status;
+    r.wave_err = sm.abort_err;
+    r.max_intervals = max_intervals > sm.max_up ? max_intervals : sm.max_up;
+    r.total_intervals = total_intervals + sm.total_up;
+    r.n_segments = 0;
+    r.n_equality = 0;
+    r.n_serial_env = n_serial + sm.serial_up;
+    r.step_reached = t;
+    if (status == 0) {
+      minimize_wave(view_of(sm.down[b]), sm.n_down[b], &r.best_cost, &r.best_log_mean,
+                    &r.prev_seg_end, &r.prev_log_mean);
+    }
+    if (lane == 0) a.result[p] = r;
+  }
+}
+
+/* Decode the optimal segmentation (drv:399-442). */
+__global__ __launch_bounds__(64) void fpop_backtrack_kernel(DeviceArgs a) {
+  const int p = (int)blockIdx.x;
+  const int lane = lane_id();
+  ProbResult r = a.result[p];
+  if (r.status != 0) return;
+  const int N = a.contig_n[a.prob_contig[p]];
+  const unsigned long long fn0 = (unsigned long long)a.prob_fn_off[p];
+  int *seg_start = a.seg_start + a.prob_seg_off[p];
+  double *seg_mean = a.seg_mean + a.prob_seg_off[p];
+  double best_log_mean = r.best_log_mean;
+  double prev_log_mean = r.prev_log_mean;
+  int prev_seg_end = r.prev_seg_end;
+  int prev_seg_offset = 0;
+  int n_seg = 0, n_eq = 0, status = 0;
+  while (0 <= prev_seg_end) {
+    if (n_seg >= N) { /* more segments than data points: cannot happen for a valid store */
+      status = PST_BACKTRACK;
+      break;
+    }
+    unsigned long long ref = a.fn_ref[fn0 + (unsigned long long)(prev_seg_offset + prev_seg_end)];
+    unsigned long long off = ref >> FN_COUNT_BITS;
+    int n = (int)(ref & ((1ull << FN_COUNT_BITS) - 1));
+    if (lane == 0) {
+      seg_start[n_seg] = prev_seg_end;
+      seg_mean[n_seg] = psd_exp(best_log_mean);
+    }
+    n_seg++;
+    prev_seg_offset = prev_seg_offset == 0 ? N : 0;
+    if (prev_log_mean != PSD_INF) {
+      best_log_mean = prev_log_mean; /* equality constraint inactive */
+    } else {
+      n_eq++;
+    }
+    /* findMean (fpl:643-653) on the restored function (drv:44-54): piece k spans
+     * [max_{k-1}, max_k], the first from -Inf; the first match wins. */
+    bool found = false;
+    for (int base = 0; base < n; base += WAVE) {
+      int k = base + lane;
+      bool hit = false;
+      int di = 0;
+      double prv = 0.0;
+      if (k < n) {
+        double mxk = a.ar_mx[off + k];
+        double mnk = k == 0 ? -PSD_INF : a.ar_mx[off + k - 1];
+        di = a.ar_di[off + k];
+        prv = a.ar_prv[off + k];
+        hit = mnk <= best_log_mean && best_log_mean <= mxk;
+      }
+      unsigned long long m = ballot(hit);
+      if (m) {
+        int src = ctz64(m);
+        prev_seg_end = shfl_i(di, src);
+        prev_log_mean = shfl_d(prv, src);
+        found = true;
+        break;
+      }
+    }
+    if (!found) {
+      status = PST_BACKTRACK;
+      break;
+    }
+  }
+  if (lane == 0) {
+    if (status == 0) {
+      seg_start[n_seg] = -1;
+      seg_mean[n_seg] = psd_exp(best_log_mean);
+      n_seg++;
+    }
+    a.result[p].n_segments = n_seg;
+    a.result[p].n_equality = n_eq;
+    a.result[p].status = status;
+  }
+}
+
+__global__ void math_probe_kernel(int op, int n, const double *x, double *y) {
+  int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < n) y[i] = op == 0 ? psd_exp(x[i]) : psd_log(x[i]);
+}
+
+}  // namespace psd
+#endif

@@ -1,0 +1,921 @@
+/* fpop_wave.h -- wavefront-level operations on piecewise Poisson-loss functions.
+ *
+ * One gfx950 wavefront (64 lanes) owns one cost function.  A function is a list of pieces
+ * in struct-of-arrays form (LDS when it fits, an HBM scratch area otherwise); lane i works
+ * on piece / merged interval i (in chunks of 64 for longer lists).
+ *
+ * These are re-designs, not translations, of the reference's sequential std::list walks
+ * (/root/reference/src/funPieceListLog.cpp, "fpl"):
+ *   min_less_wave  <- set_to_min_less_of   fpl:236-437
+ *   min_more_wave  <- set_to_min_more_of   fpl:439-616
+ *   min_env_wave   <- set_to_min_env_of + push_min_pieces + push_piece  fpl:832-860,870-1285
+ * Each produces bit-identical lists to the sequential algorithm:
+ *   - everything a walk computes about a piece that does not depend on the walk's state
+ *     (end costs, argmin, the "search mode" decision) is evaluated by all lanes at once;
+ *   - the walk's state machine (search for a minimum / follow a constant) then advances
+ *     with ballots; while following a constant every remaining piece tests the crossing
+ *     speculatively (root finding in parallel) and the lowest (highest) lane with an event
+ *     wins, which is exactly the piece the sequential walk would have stopped at;
+ *   - the min-envelope's merged intervals are independent given the two input lists, so
+ *     each lane classifies one interval (up to two Newton solves) and emits 1-3 candidate
+ *     pieces; candidates are compacted with a ballot/prefix scan.  push_piece's coalescing
+ *     compares against the run head with a non-transitive tolerance, so the scan is only
+ *     used when every "same function" decision is also a bitwise equality (then comparing
+ *     with the predecessor is equivalent); otherwise lane 0 replays the interval list
+ *     sequentially (rare; counted in the stats).
+ */
+#ifndef PSD_FPOP_WAVE_H
+#define PSD_FPOP_WAVE_H
+
+#include "fpop_pieces.h"
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+namespace psd {
+
+/* struct-of-arrays view of one piece list (funPieceListLog.h:11-34 fields) */
+struct ListView {
+  double *Lin, *Log, *Con, *mn, *mx, *prv;
+  int *di;
+};
+
+PSD_D ListView list_offset(const ListView &L, int off) {
+  ListView r;
+  r.Lin = L.Lin + off;
+  r.Log = L.Log + off;
+  r.Con = L.Con + off;
+  r.mn = L.mn + off;
+  r.mx = L.mx + off;
+  r.prv = L.prv + off;
+  r.di = L.di + off;
+  return r;
+}
+
+PSD_D Coef load_coef(const ListView &L, int i) {
+  Coef c;
+  c.Linear = L.Lin[i];
+  c.Log = L.Log[i];
+  c.Constant = L.Con[i];
+  return c;
+}
+
+PSD_D void store_piece(const ListView &L, int i, const Coef &c, double mn, double mx, int di,
+                       double prv) {
+  L.Lin[i] = c.Linear;
+  L.Log[i] = c.Log;
+  L.Con[i] = c.Constant;
+  L.mn[i] = mn;
+  L.mx[i] = mx;
+  L.di[i] = di;
+  L.prv[i] = prv;
+}
+
+/* per-wave temporaries, one slot per input piece / merged interval */
+struct WaveScratch {
+  double *lc, *rc, *mu, *muc; /* cost at left end, right end, argmin, cost at argmin */
+  int *cls;                   /* search-mode decision */
+  int *iv;                    /* merged interval k -> (i1 << 16) | i2 */
+};
+
+enum { CLS_STORE = 0, CLS_CONST_EDGE = 1, CLS_CONST_MU = 2 };
+
+/* error bits reported by the wave ops (the reference would throw / loop / read a sentinel) */
+enum {
+  WERR_OVERFLOW = 1,      /* output does not fit `cap`: caller retries in spill mode */
+  WERR_REF_THROW = 2,     /* fpl:380 decreasing degenerate linear piece */
+  WERR_SENTINEL = 4,      /* push_min_pieces neighbour outside the list */
+  WERR_ZERO_INTERVAL = 8, /* fpl:933 zero-size merged interval */
+};
+
+/* ------------------------------------------------------------------------------------- */
+/* min-less: out(x) = min_{y<=x} in(y).  Returns the number of output pieces (all with
+ * data_i = data_i_out, as the driver's set_prev_seg_end() does next, and Constant shifted
+ * by `add_const`, as its add(0,0,penalty/cum_weight_prev) does: PeakSegFPOPLog.cpp:290-296). */
+PSD_D int min_less_wave(const ListView &in, int n, const ListView &out, int cap,
+                        const WaveScratch &s, int data_i_out, double add_const, int *err) {
+  const int lane = lane_id();
+  /* pass 1: state-independent quantities of every piece (fpl:245-246,310-311) */
+  for (int base = 0; base < n; base += WAVE) {
+    int i = base + lane;
+    if (i < n) {
+      Coef c = load_coef(in, i);
+      double lc = get_cost(c, in.mn[i]);
+      double rc = get_cost(c, in.mx[i]);
+      double mu = 0.0, muc = 0.0;
+      if (c.Log != 0) {
+        mu = argmin(c);
+        muc = get_cost(c, mu);
+      }
+      s.lc[i] = lc;
+      s.rc[i] = rc;
+      s.mu[i] = mu;
+      s.muc[i] = muc;
+    }
+  }
+  wave_sync();
+  /* pass 2: what the walk does with piece i when it reaches it in search mode */
+  for (int base = 0; base < n; base += WAVE) {
+    int i = base + lane;
+    if (i < n) {
+      double Log_i = in.Log[i];
+      double lc = s.lc[i], rc = s.rc[i];
+      bool has_next = i + 1 < n;
+      double next_left_cost = has_next ? s.lc[i + 1] : PSD_INF;
+      int cls;
+      if (Log_i == 0) { /* fpl:256-308 */
+        double right_left_diff = rc - lc;
+        bool right_left_equal = right_left_diff < NEWTON_EPSILON;
+        bool next_cost_more_than_left = true;
+        if (has_next) {
+          double next_left_diff = next_left_cost - lc;
+          next_cost_more_than_left = NEWTON_EPSILON < next_left_diff;
+        }
+        cls = (next_cost_more_than_left && !right_left_equal) ? CLS_CONST_EDGE : CLS_STORE;
+      } else { /* fpl:309-366 */
+        double mu = s.mu[i], mu_cost = s.muc[i];
+        bool next_ok = true;
+        if (has_next) next_ok = NEWTON_EPSILON < next_left_cost - mu_cost;
+        bool cost_ok = NEWTON_EPSILON < rc - mu_cost && next_ok;
+        if (mu <= in.mn[i] && cost_ok) {
+          cls = CLS_CONST_EDGE;
+        } else if (mu < in.mx[i] && cost_ok) {
+          cls = CLS_CONST_MU;
+        } else {
+          cls = CLS_STORE;
+        }
+      }
+      s.cls[i] = cls;
+    }
+  }
+  wave_sync();
+
+  int n_out = 0;
+  int i0 = 0;
+  double prev_min_log_mean = in.mn[0];
+  for (;;) {
+    /* ---- search mode: first piece j >= i0 that starts a constant ---- */
+    int j = n;
+    for (int base = i0 & ~(WAVE - 1); base < n; base += WAVE) {
+      int i = base + lane;
+      bool hit = i >= i0 && i < n && s.cls[i] != CLS_STORE;
+      unsigned long long m = ballot(hit);
+      if (m) {
+        j = base + ctz64(m);
+        break;
+      }
+    }
+    /* pieces i0..j-1 are kept as they are (fpl:303-307,361-364) */
+    int cnt = j - i0;
+    if (n_out + cnt + 2 > cap) {
+      *err |= WERR_OVERFLOW;
+      return 0;
+    }
+    for (int base = i0; base < j; base += WAVE) {
+      int i = base + lane;
+      if (i < j) {
+        Coef c = load_coef(in, i);
+        c.Constant = c.Constant + add_const;
+        c.Linear = c.Linear + 0.0;
+        c.Log = c.Log + 0.0;
+        double lo = (i == i0) ? prev_min_log_mean : in.mn[i];
+        store_piece(out, n_out + (i - i0), c, lo, in.mx[i], data_i_out, PSD_INF);
+      }
+    }
+    n_out += cnt;
+    if (cnt > 0) prev_min_log_mean = in.mx[j - 1];
+    if (j == n) break;
+    /* ---- piece j starts a constant piece ---- */
+    double prev_min_cost, prev_best_log_mean;
+    if (s.cls[j] == CLS_CONST_MU) { /* fpl:337-355 */
+      double mu = s.mu[j];
+      if (prev_min_log_mean < mu) {
+        if (lane == 0) {
+          Coef c = load_coef(in, j);
+          c.Constant = c.Constant + add_const;
+          c.Linear = c.Linear + 0.0;
+          c.Log = c.Log + 0.0;
+          store_piece(out, n_out, c, prev_min_log_mean, mu, data_i_out, PSD_INF);
+        }
+        n_out++;
+      }
+      prev_min_log_mean = mu;
+      prev_best_log_mean = mu;
+      prev_min_cost = s.muc[j];
+    } else { /* fpl:288-292,328-336 */
+      prev_min_cost = s.lc[j];
+      prev_best_log_mean = in.mn[j];
+    }
+    /* ---- constant mode: first piece k > j where the constant ends (fpl:367-422) ---- */
+    int k_ev = -1;
+    bool ev_inside = false;
+    double ev_mu = 0.0;
+    for (int base = j + 1; base < n; base += WAVE) {
+      int k = base + lane;
+      bool inside = false, at_right = false, bad = false;
+      double mu = PSD_INF;
+      if (k < n) {
+        Coef c = load_coef(in, k);
+        if (c.Log == 0) {
+          if (c.Linear < 0) bad = true; /* fpl:378-380 */
+        } else {
+          if (has_two_roots(c, prev_min_cost)) {
+            mu = get_smaller_root(c, in.mn[k], prev_min_cost);
+            inside = in.mn[k] < mu && mu < in.mx[k];
+          }
+          if (!inside) at_right = s.rc[k] <= prev_min_cost + NEWTON_EPSILON;
+        }
+      }
+      unsigned long long m_ev = ballot(inside || at_right);
+      unsigned long long m_bad = ballot(bad);
+      unsigned long long visited = m_ev ? lanes_below(ctz64(m_ev)) : ~0ull;
+      if (m_bad & visited) *err |= WERR_REF_THROW;
+      if (m_ev) {
+        int src = ctz64(m_ev);
+        k_ev = base + src;
+        ev_inside = shfl_i(inside ? 1 : 0, src) != 0;
+        ev_mu = shfl_d(mu, src);
+        break;
+      }
+    }
+    Coef cc;
+    cc.Linear = 0.0 + 0.0;
+    cc.Log = 0.0 + 0.0;
+    cc.Constant = prev_min_cost + add_const;
+    if (k_ev < 0) { /* constant runs to the end (fpl:429-436) */
+      if (lane == 0)
+        store_piece(out, n_out, cc, prev_min_log_mean, in.mx[n - 1], data_i_out,
+                    prev_best_log_mean);
+      n_out++;
+      break;
+    }
+    if (ev_inside) { /* crossing inside piece k: revisit k in search mode (fpl:397-408) */
+      if (lane == 0)
+        store_piece(out, n_out, cc, prev_min_log_mean, ev_mu, data_i_out, prev_best_log_mean);
+      n_out++;
+      prev_min_log_mean = ev_mu;
+      i0 = k_ev;
+    } else { /* constant ends on the right end of piece k (fpl:410-420) */
+      double mxk = in.mx[k_ev];
+      if (lane == 0)
+        store_piece(out, n_out, cc, prev_min_log_mean, mxk, data_i_out, prev_best_log_mean);
+      n_out++;
+      prev_min_log_mean = mxk;
+      i0 = k_ev + 1;
+      if (i0 == n) break;
+    }
+  }
+  wave_sync();
+  return n_out;
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* min-more: out(x) = min_{y>=x} in(y).  The reference builds the list with emplace_front;
+ * here pieces are written downwards from out[cap-1], and the result is out[head..cap). The
+ * return value is the piece count; *head_out = cap - count.  data_i as for min_less. */
+PSD_D int min_more_wave(const ListView &in, int n, const ListView &out, int cap,
+                        const WaveScratch &s, int data_i_out, int *head_out, int *err) {
+  const int lane = lane_id();
+  for (int base = 0; base < n; base += WAVE) {
+    int i = base + lane;
+    if (i < n) {
+      Coef c = load_coef(in, i);
+      double lc = get_cost(c, in.mn[i]);
+      double rc = get_cost(c, in.mx[i]);
+      double mu = 0.0, muc = 0.0;
+      if (c.Log != 0) {
+        mu = argmin(c);
+        muc = get_cost(c, mu);
+      }
+      s.lc[i] = lc;
+      s.rc[i] = rc;
+      s.mu[i] = mu;
+      s.muc[i] = muc;
+    }
+  }
+  wave_sync();
+  for (int base = 0; base < n; base += WAVE) {
+    int i = base + lane;
+    if (i < n) {
+      int cls;
+      if (in.Log[i] == 0) { /* fpl:458-467 */
+        cls = CLS_STORE;
+      } else { /* fpl:468-548 */
+        double mu = s.mu[i], mu_cost = s.muc[i];
+        bool prev_ok = true;
+        if (i > 0) {
+          double prev_cost_right = s.rc[i - 1];
+          prev_ok = NEWTON_EPSILON < prev_cost_right - mu_cost;
+        }
+        double this_cost_left = s.lc[i];
+        if (in.mx[i] <= mu) {
+          double this_cost_diff = this_cost_left - s.rc[i];
+          cls = (NEWTON_EPSILON < this_cost_diff) ? CLS_CONST_EDGE : CLS_STORE;
+        } else if (in.mn[i] < mu && NEWTON_EPSILON < this_cost_left - mu_cost && prev_ok) {
+          cls = CLS_CONST_MU;
+        } else {
+          cls = CLS_STORE;
+        }
+      }
+      s.cls[i] = cls;
+    }
+  }
+  wave_sync();
+
+  int n_out = 0; /* pieces written so far; piece p lives at out[cap-1-p] */
+  int i0 = n - 1;
+  double prev_max_log_mean = in.mx[n - 1];
+  const Coef czero = {0.0, 0.0, 0.0};
+  for (;;) {
+    /* ---- search mode, walking down from i0: first piece j <= i0 starting a constant ---- */
+    int j = -1;
+    for (int base = i0 | (WAVE - 1); base >= 0; base -= WAVE) { /* base = top of a chunk */
+      int i = base - lane;
+      bool hit = i <= i0 && i >= 0 && s.cls[i] != CLS_STORE;
+      unsigned long long m = ballot(hit);
+      if (m) {
+        j = base - ctz64(m);
+        break;
+      }
+    }
+    int cnt = i0 - j;
+    if (n_out + cnt + 2 > cap) {
+      *err |= WERR_OVERFLOW;
+      return 0;
+    }
+    for (int base = i0; base > j; base -= WAVE) {
+      int i = base - lane;
+      if (i > j) {
+        Coef c = load_coef(in, i);
+        double hi = (i == i0) ? prev_max_log_mean : in.mx[i];
+        store_piece(out, cap - 1 - (n_out + (i0 - i)), c, in.mn[i], hi, data_i_out, PSD_INF);
+      }
+    }
+    n_out += cnt;
+    if (cnt > 0) prev_max_log_mean = in.mn[j + 1];
+    if (j < 0) break;
+    double prev_min_cost, prev_best_log_mean;
+    if (s.cls[j] == CLS_CONST_MU) { /* fpl:524-537 */
+      double mu = s.mu[j];
+      if (mu < prev_max_log_mean) {
+        if (lane == 0)
+          store_piece(out, cap - 1 - n_out, load_coef(in, j), mu, prev_max_log_mean, data_i_out,
+                      PSD_INF);
+        n_out++;
+      }
+      prev_max_log_mean = mu;
+      prev_best_log_mean = mu;
+      prev_min_cost = s.muc[j];
+    } else { /* fpl:500-510 */
+      prev_min_cost = s.rc[j];
+      prev_best_log_mean = in.mx[j];
+    }
+    /* ---- constant mode: highest piece k < j where the constant ends (fpl:549-602) ---- */
+    int k_ev = -1;
+    bool ev_inside = false;
+    double ev_mu = 0.0;
+    for (int base = j - 1; base >= 0; base -= WAVE) {
+      int k = base - lane;
+      bool inside = false, at_left = false;
+      double mu = PSD_INF;
+      if (k >= 0) {
+        Coef c = load_coef(in, k);
+        if (c.Log == 0) {
+          mu = psd_log((prev_min_cost - c.Constant) / c.Linear); /* fpl:563 */
+        } else {
+          if (has_two_roots(c, prev_min_cost)) {
+            mu = get_larger_root(c, in.mx[k], prev_min_cost);
+          }
+        }
+        inside = in.mn[k] < mu && mu < in.mx[k];
+        if (!inside) at_left = s.lc[k] <= prev_min_cost + NEWTON_EPSILON;
+      }
+      unsigned long long m_ev = ballot(inside || at_left);
+      if (m_ev) {
+        int src = ctz64(m_ev);
+        k_ev = base - src;
+        ev_inside = shfl_i(inside ? 1 : 0, src) != 0;
+        ev_mu = shfl_d(mu, src);
+        break;
+      }
+    }
+    Coef cc = czero;
+    cc.Constant = prev_min_cost;
+    if (k_ev < 0) { /* constant runs to the start (fpl:608-615) */
+      if (lane == 0)
+        store_piece(out, cap - 1 - n_out, cc, in.mn[0], prev_max_log_mean, data_i_out,
+                    prev_best_log_mean);
+      n_out++;
+      break;
+    }
+    if (ev_inside) { /* fpl:578-590 */
+      if (lane == 0)
+        store_piece(out, cap - 1 - n_out, cc, ev_mu, prev_max_log_mean, data_i_out,
+                    prev_best_log_mean);
+      n_out++;
+      prev_max_log_mean = ev_mu;
+      i0 = k_ev;
+    } else { /* fpl:591-601 */
+      double mnk = in.mn[k_ev];
+      if (lane == 0)
+        store_piece(out, cap - 1 - n_out, cc, mnk, prev_max_log_mean, data_i_out,
+                    prev_best_log_mean);
+      n_out++;
+      prev_max_log_mean = mnk;
+      i0 = k_ev - 1;
+      if (i0 < 0) break;
+    }
+  }
+  wave_sync();
+  *head_out = cap - n_out;
+  return n_out;
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* candidates emitted for one merged interval: up to three (source, [lo,hi]) in order */
+struct Cands {
+  int n;
+  int src0, src1, src2; /* 0: piece of fun1, 1: piece of fun2 */
+  double lo0, hi0, lo1, hi1, lo2, hi2;
+};
+
+/* fpl:1261-1267: zero/negative-width pieces are never stored */
+PSD_D void cand_push(Cands &c, int src, double lo, double hi) {
+  if (hi <= lo) return;
+  if (c.n == 0) {
+    c.src0 = src;
+    c.lo0 = lo;
+    c.hi0 = hi;
+  } else if (c.n == 1) {
+    c.src1 = src;
+    c.lo1 = lo;
+    c.hi1 = hi;
+  } else {
+    c.src2 = src;
+    c.lo2 = lo;
+    c.hi2 = hi;
+  }
+  c.n++;
+}
+
+/* push_min_pieces (fpl:870-1259) for one merged interval [last_min, first_max] of
+ * it1 = c1, it2 = c2, given the two neighbour-equality flags. */
+PSD_D void env_interval(const Coef &c1, const Coef &c2, double last_min_log_mean,
+                        double first_max_log_mean, bool same_at_left, bool same_at_right,
+                        Cands &out) {
+  out.n = 0;
+  const double a = last_min_log_mean, b = first_max_log_mean;
+  if (same_funs(c1, c2)) { /* fpl:945-951 */
+    cand_push(out, 0, a, b);
+    return;
+  }
+  Coef d;
+  d.Linear = c1.Linear - c2.Linear;
+  d.Log = c1.Log - c2.Log;
+  d.Constant = c1.Constant - c2.Constant;
+  double mid_mean = (psd_exp(b) + psd_exp(a)) / 2; /* fpl:960 */
+  double cost_diff_mid = get_cost(d, psd_log(mid_mean));
+  if (same_at_left && same_at_right) { /* fpl:963-971 */
+    cand_push(out, cost_diff_mid < 0 ? 0 : 1, a, b);
+    return;
+  }
+  if (d.Log == 0) { /* fpl:973-1019 */
+    if (d.Linear == 0) {
+      cand_push(out, d.Constant < 0 ? 0 : 1, a, b);
+      return;
+    }
+    if (d.Constant == 0) {
+      cand_push(out, d.Linear < 0 ? 0 : 1, a, b);
+      return;
+    }
+    double x = psd_log(-d.Constant / d.Linear);
+    if (a < x && x < b) {
+      int first = (0 < d.Linear) ? 0 : 1;
+      cand_push(out, first, a, x);
+      cand_push(out, 1 - first, x, b);
+      return;
+    }
+    cand_push(out, cost_diff_mid < 0 ? 0 : 1, a, b);
+    return;
+  }
+  double cost_diff_left = get_cost(d, a);
+  double cost_diff_right = get_cost(d, b);
+  bool two_roots = has_two_roots(d, 0.0);
+  double smaller_log_mean = PSD_INF, larger_log_mean = PSD_INF;
+  if (two_roots) {
+    smaller_log_mean = get_smaller_root(d, a, 0.0);
+    larger_log_mean = get_larger_root(d, b, 0.0);
+  }
+  if (same_at_right) { /* fpl:1029-1093 */
+    if (two_roots) {
+      double x = smaller_log_mean;
+      double opt = argmin(d);
+      if (a < x && x < opt && opt < b) {
+        int first = (cost_diff_left < 0) ? 0 : 1;
+        cand_push(out, first, a, x);
+        cand_push(out, 1 - first, x, b);
+        return;
+      }
+      bool it1_smaller_at_mean0 = 0 < d.Log;
+      if (x < a) {
+        cand_push(out, it1_smaller_at_mean0 ? 1 : 0, a, b);
+      } else {
+        cand_push(out, it1_smaller_at_mean0 ? 0 : 1, a, b);
+      }
+      return;
+    }
+    cand_push(out, cost_diff_mid < 0 ? 0 : 1, a, b);
+    return;
+  }
+  if (same_at_left) { /* fpl:1094-1123 */
+    if (two_roots) {
+      double x = larger_log_mean;
+      double opt = argmin(d);
+      if (a < opt && opt < x && x < b) {
+        int first = (cost_diff_right < 0) ? 1 : 0;
+        cand_push(out, first, a, x);
+        cand_push(out, 1 - first, x, b);
+        return;
+      }
+    }
+    cand_push(out, cost_diff_mid < 0 ? 0 : 1, a, b);
+    return;
+  }
+  /* equal on neither side (fpl:1124-1258) */
+  double first_log_mean = PSD_INF, second_log_mean = PSD_INF;
+  if (two_roots) {
+    bool larger_inside = a < larger_log_mean && larger_log_mean < b;
+    bool smaller_inside =
+        a < smaller_log_mean && 0 < psd_exp(smaller_log_mean) && smaller_log_mean < b;
+    if (larger_inside) {
+      if (smaller_inside && smaller_log_mean < larger_log_mean) {
+        first_log_mean = smaller_log_mean;
+        second_log_mean = larger_log_mean;
+      } else {
+        first_log_mean = larger_log_mean;
+      }
+    } else {
+      if (smaller_inside) {
+        first_log_mean = smaller_log_mean;
+      }
+    }
+  }
+  if (second_log_mean != PSD_INF) {
+    bool it1_larger_before;
+    if (second_log_mean - first_log_mean < first_log_mean - a) {
+      double before_mean = (psd_exp(a) + psd_exp(first_log_mean)) / 2;
+      double cost_diff_before = get_cost(d, psd_log(before_mean));
+      it1_larger_before = cost_diff_before < 0;
+    } else {
+      double log_mean_between = (first_log_mean + second_log_mean) / 2;
+      double cost_diff_between = get_cost(d, log_mean_between);
+      it1_larger_before = !(cost_diff_between < 0);
+    }
+    int first = it1_larger_before ? 0 : 1;
+    cand_push(out, first, a, first_log_mean);
+    cand_push(out, 1 - first, first_log_mean, second_log_mean);
+    cand_push(out, first, second_log_mean, b);
+  } else if (first_log_mean != PSD_INF) {
+    double before_mean = (psd_exp(a) + psd_exp(first_log_mean)) / 2;
+    double cost_diff_before = get_cost(d, psd_log(before_mean));
+    double after_mean = (b + first_log_mean) / 2; /* a log-mean, fpl:1216 */
+    double cost_diff_after = get_cost(d, after_mean);
+    if (cost_diff_before < 0) {
+      if (cost_diff_after < 0) {
+        cand_push(out, 0, a, b);
+      } else {
+        cand_push(out, 0, a, first_log_mean);
+        cand_push(out, 1, first_log_mean, b);
+      }
+    } else {
+      if (cost_diff_after < 0) {
+        cand_push(out, 1, a, first_log_mean);
+        cand_push(out, 0, first_log_mean, b);
+      } else {
+        cand_push(out, 1, a, b);
+      }
+    }
+  } else {
+    double cost_diff;
+    if (absd(cost_diff_mid) < NEWTON_EPSILON) {
+      cost_diff = cost_diff_right;
+    } else {
+      cost_diff = cost_diff_mid;
+    }
+    cand_push(out, cost_diff < 0 ? 0 : 1, a, b);
+  }
+}
+
+/* number of pieces with max_log_mean < x in a list sorted by max_log_mean */
+PSD_D int lower_bound_mx(const double *mx, int n, double x) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (mx[mid] < x) {
+      lo = mid + 1;
+    } else {
+      hi = mid;
+    }
+  }
+  return lo;
+}
+
+/* Everything push_min_pieces needs for merged interval (i1,i2): loads the two pieces and
+ * the neighbours it inspects (fpl:876-932), classifies, returns candidates. */
+PSD_D void env_interval_at(const ListView &f1, int n1, const ListView &f2, int n2, int i1, int i2,
+                           Cands &cands, Coef &c1, Coef &c2, int *err) {
+  c1 = load_coef(f1, i1);
+  c2 = load_coef(f2, i2);
+  double mn1 = f1.mn[i1], mx1 = f1.mx[i1], mn2 = f2.mn[i2], mx2 = f2.mx[i2];
+  bool same_at_left, same_at_right;
+  double last_min_log_mean, first_max_log_mean;
+  bool sentinel = false;
+  if (mn1 < mn2) {
+    if (i2 == 0) sentinel = true;
+    same_at_left = !sentinel && same_funs(load_coef(f2, i2 - 1), c1);
+    last_min_log_mean = mn2;
+  } else {
+    last_min_log_mean = mn1;
+    if (mn2 < mn1) {
+      if (i1 == 0) sentinel = true;
+      same_at_left = !sentinel && same_funs(load_coef(f1, i1 - 1), c2);
+    } else {
+      if (i1 == 0 && i2 == 0) {
+        same_at_left = false;
+      } else {
+        if (i1 == 0 || i2 == 0) sentinel = true;
+        same_at_left = !sentinel && same_funs(load_coef(f1, i1 - 1), load_coef(f2, i2 - 1));
+      }
+    }
+  }
+  bool sentinel_r = false;
+  if (mx1 < mx2) {
+    if (i1 + 1 >= n1) sentinel_r = true;
+    same_at_right = !sentinel_r && same_funs(load_coef(f1, i1 + 1), c2);
+    first_max_log_mean = mx1;
+  } else {
+    first_max_log_mean = mx2;
+    if (mx2 < mx1) {
+      if (i2 + 1 >= n2) sentinel_r = true;
+      same_at_right = !sentinel_r && same_funs(c1, load_coef(f2, i2 + 1));
+    } else {
+      if (i1 + 1 == n1 && i2 + 1 == n2) {
+        same_at_right = false;
+      } else {
+        if (i1 + 1 >= n1 || i2 + 1 >= n2) sentinel_r = true;
+        same_at_right =
+            !sentinel_r && same_funs(load_coef(f1, i1 + 1), load_coef(f2, i2 + 1));
+      }
+    }
+  }
+  if (sentinel || sentinel_r) *err |= WERR_SENTINEL;
+  cands.n = 0;
+  if (last_min_log_mean == first_max_log_mean) { /* fpl:933-944 */
+    *err |= WERR_ZERO_INTERVAL;
+    return;
+  }
+  env_interval(c1, c2, last_min_log_mean, first_max_log_mean, same_at_left, same_at_right,
+               cands);
+}
+
+/* push_piece's "same as last" test (fpl:1270-1273) */
+PSD_D bool coalesces(const Coef &last, double last_prv, int last_di, const Coef &c, double prv,
+                     int di) {
+  return same_funs(last, c) && prv == last_prv && di == last_di;
+}
+PSD_D bool bit_identical(const Coef &last, double last_prv, int last_di, const Coef &c,
+                         double prv, int di) {
+  return psd_d2u(last.Linear) == psd_d2u(c.Linear) && psd_d2u(last.Log) == psd_d2u(c.Log) &&
+         psd_d2u(last.Constant) == psd_d2u(c.Constant) && psd_d2u(last_prv) == psd_d2u(prv) &&
+         last_di == di;
+}
+
+/* min-envelope: out = pointwise min(f1, f2).  Returns the piece count.
+ * *n_serial is incremented when the sequential replay was needed. */
+PSD_D int min_env_wave(const ListView &f1, int n1, const ListView &f2, int n2,
+                       const ListView &out, int cap, const WaveScratch &s, int iv_cap,
+                       int *n_serial, int *err) {
+  const int lane = lane_id();
+  /* ---- merged-interval table: interval k ends at the k-th distinct max_log_mean ---- */
+  int K;
+  {
+    int dup_before = 0; /* ends of f1 that are also ends of f2, among earlier chunks */
+    for (int base = 0; base < n1; base += WAVE) {
+      int i = base + lane;
+      bool valid = i < n1;
+      int p = 0;
+      bool dup = false;
+      if (valid) {
+        double x = f1.mx[i];
+        p = lower_bound_mx(f2.mx, n2, x);
+        dup = p < n2 && f2.mx[p] == x;
+      }
+      unsigned long long md = ballot(dup);
+      if (valid) {
+        int k = i + p - (dup_before + popc64(md & lanes_below(lane)));
+        if (k < iv_cap) s.iv[k] = (i << 16) | p;
+      }
+      dup_before += popc64(md);
+    }
+    int dup_total = dup_before;
+    dup_before = 0;
+    for (int base = 0; base < n2; base += WAVE) {
+      int j = base + lane;
+      bool valid = j < n2;
+      int q = 0;
+      bool dup = false;
+      if (valid) {
+        double x = f2.mx[j];
+        q = lower_bound_mx(f1.mx, n1, x);
+        dup = q < n1 && f1.mx[q] == x;
+      }
+      unsigned long long md = ballot(dup);
+      if (valid && !dup) {
+        int k = j + q - (dup_before + popc64(md & lanes_below(lane)));
+        if (k < iv_cap) s.iv[k] = (q << 16) | j;
+      }
+      dup_before += popc64(md);
+    }
+    K = n1 + n2 - dup_total;
+  }
+  if (K > iv_cap) {
+    *err |= WERR_OVERFLOW;
+    return 0;
+  }
+  wave_sync();
+
+  /* ---- one lane per interval; ballot/prefix-scan compaction ---- */
+  int n_out = 0;
+  bool need_serial = false;
+  /* source of the last candidate emitted so far (carried across chunks) */
+  Coef last_c = {0.0, 0.0, 0.0};
+  double last_prv = 0.0;
+  int last_di = 0;
+  bool have_last = false;
+  for (int base = 0; base < K; base += WAVE) {
+    int k = base + lane;
+    bool valid = k < K;
+    Cands cd;
+    cd.n = 0;
+    Coef c1 = {0.0, 0.0, 0.0}, c2 = {0.0, 0.0, 0.0};
+    double prv1 = 0.0, prv2 = 0.0;
+    int di1 = 0, di2 = 0, i1 = 0, i2 = 0;
+    if (valid) {
+      int e = s.iv[k];
+      i1 = e >> 16;
+      i2 = e & 0xffff;
+      env_interval_at(f1, n1, f2, n2, i1, i2, cd, c1, c2, err);
+      prv1 = f1.prv[i1];
+      di1 = f1.di[i1];
+      prv2 = f2.prv[i2];
+      di2 = f2.di[i2];
+    }
+    /* first / last candidate of this lane */
+    Coef fc = cd.src0 ? c2 : c1;
+    double fprv = cd.src0 ? prv2 : prv1;
+    int fdi = cd.src0 ? di2 : di1;
+    int lsrc = cd.n == 3 ? cd.src2 : (cd.n == 2 ? cd.src1 : cd.src0);
+    Coef lc = lsrc ? c2 : c1;
+    double lprv = lsrc ? prv2 : prv1;
+    int ldi = lsrc ? di2 : di1;
+    bool has = valid && cd.n > 0;
+    unsigned long long m_has = ballot(has);
+    /* predecessor = last candidate of the nearest lower lane that has one, else carry */
+    unsigned long long below = m_has & lanes_below(lane);
+    int psrc = below ? msb64(below) : 0;
+    Coef pc;
+    pc.Linear = shfl_d(lc.Linear, psrc);
+    pc.Log = shfl_d(lc.Log, psrc);
+    pc.Constant = shfl_d(lc.Constant, psrc);
+    double pprv = shfl_d(lprv, psrc);
+    int pdi = shfl_i(ldi, psrc);
+    bool have_pred = below != 0 || have_last;
+    if (!below) {
+      pc = last_c;
+      pprv = last_prv;
+      pdi = last_di;
+    }
+    bool head0 = true; /* does the first candidate start a new output piece? */
+    bool fuzzy = false;
+    if (has && have_pred) {
+      bool co = coalesces(pc, pprv, pdi, fc, fprv, fdi);
+      bool bi = bit_identical(pc, pprv, pdi, fc, fprv, fdi);
+      head0 = !co;
+      fuzzy = co && !bi;
+    }
+    /* candidates 2 and 3 of a lane alternate it1/it2 with same_funs(it1,it2) false, so
+     * they always start a new piece -- provided the run they follow is bit-identical to
+     * its head, which `fuzzy` checks. */
+    if (ballot(fuzzy)) {
+      need_serial = true;
+      break;
+    }
+    int heads = has ? ((head0 ? 1 : 0) + (cd.n - 1)) : 0;
+    unsigned long long hb0 = ballot((heads & 1) != 0);
+    unsigned long long hb1 = ballot((heads & 2) != 0);
+    unsigned long long lb = lanes_below(lane);
+    int heads_before = popc64(hb0 & lb) + 2 * popc64(hb1 & lb);
+    int heads_total = popc64(hb0) + 2 * popc64(hb1);
+    if (n_out + heads_total > cap) {
+      *err |= WERR_OVERFLOW;
+      return 0;
+    }
+    if (has) {
+      /* slot of the piece that candidate 0 belongs to */
+      int slot = n_out + heads_before - (head0 ? 0 : 1);
+      /* is the next candidate (first of the next lane that has one) a head? */
+      if (head0) store_piece(out, slot, fc, cd.lo0, cd.hi0, fdi, fprv);
+      if (cd.n >= 2) {
+        int sl = slot + 1;
+        Coef c = cd.src1 ? c2 : c1;
+        store_piece(out, sl, c, cd.lo1, cd.hi1, cd.src1 ? di2 : di1, cd.src1 ? prv2 : prv1);
+      }
+      if (cd.n >= 3) {
+        int sl = slot + 2;
+        Coef c = cd.src2 ? c2 : c1;
+        store_piece(out, sl, c, cd.lo2, cd.hi2, cd.src2 ? di2 : di1, cd.src2 ? prv2 : prv1);
+      }
+    }
+    wave_sync();
+    /* a candidate that extends the previous piece only moves its right end; lanes write
+     * in increasing order of hi within a run, and the last one must win: do it after the
+     * heads are in place, lowest lane first is not guaranteed, so only the final member
+     * of each run writes. */
+    {
+      unsigned long long m_head0 = ballot(has && head0);
+      if (has && !head0) {
+        /* this lane's candidate 0 is the last member of its run iff the next lane that
+         * has candidates starts with a head (or there is none in this chunk: then a later
+         * chunk or nobody extends it further, and a later extension overwrites anyway) */
+        unsigned long long above = m_has & ~lb & ~(1ull << lane);
+        bool next_is_head = true;
+        if (above) {
+          int nl = ctz64(above);
+          next_is_head = ((m_head0 >> nl) & 1ull) != 0;
+        }
+        if (cd.n >= 2 || next_is_head) {
+          int slot = n_out + heads_before - 1;
+          out.mx[slot] = cd.hi0;
+        }
+      }
+    }
+    wave_sync();
+    n_out += heads_total;
+    if (m_has) {
+      int src = msb64(m_has);
+      last_c.Linear = shfl_d(lc.Linear, src);
+      last_c.Log = shfl_d(lc.Log, src);
+      last_c.Constant = shfl_d(lc.Constant, src);
+      last_prv = shfl_d(lprv, src);
+      last_di = shfl_i(ldi, src);
+      have_last = true;
+    }
+  }
+  if (need_serial) {
+    /* exact sequential replay of fpl:832-860 + push_piece on one lane */
+    (*n_serial)++;
+    int count = 0;
+    int ovf = 0;
+    if (lane == 0) {
+      for (int k = 0; k < K; k++) {
+        int e = s.iv[k];
+        int i1 = e >> 16, i2 = e & 0xffff;
+        Cands cd;
+        Coef c1, c2;
+        env_interval_at(f1, n1, f2, n2, i1, i2, cd, c1, c2, err);
+        for (int q = 0; q < cd.n; q++) {
+          int src = q == 0 ? cd.src0 : (q == 1 ? cd.src1 : cd.src2);
+          double lo = q == 0 ? cd.lo0 : (q == 1 ? cd.lo1 : cd.lo2);
+          double hi = q == 0 ? cd.hi0 : (q == 1 ? cd.hi1 : cd.hi2);
+          Coef c = src ? c2 : c1;
+          double prv = src ? f2.prv[i2] : f1.prv[i1];
+          int di = src ? f2.di[i2] : f1.di[i1];
+          if (count > 0 && coalesces(load_coef(out, count - 1), out.prv[count - 1],
+                                     out.di[count - 1], c, prv, di)) {
+            out.mx[count - 1] = hi;
+          } else {
+            if (count >= cap) {
+              ovf = 1;
+              break;
+            }
+            store_piece(out, count, c, lo, hi, di, prv);
+            count++;
+          }
+        }
+        if (ovf) break;
+      }
+    }
+    wave_sync();
+    ovf = shfl_i(ovf, 0);
+    n_out = shfl_i(count, 0);
+    if (ovf) {
+      *err |= WERR_OVERFLOW;
+      return 0;
+    }
+  }
+  return n_out;
+}
+
+}  // namespace psd
+#endif

@@ -1,0 +1,802 @@
+/* peakseg_hip.cpp -- host driver and C ABI of libpeaksegdisk_hip.so.
+ *
+ * Host-side counterpart of the reference's solver driver
+ * (/root/reference/src/PeakSegFPOPLog.cpp:143-463, "drv"): bedGraph parsing and validation,
+ * the trivial one-segment branch, upload, kernel launches, and the two output files.  The
+ * dynamic program itself only exists as HIP kernels (fpop_kernels.h): when no GPU is
+ * visible the DP branch fails with ERROR_NO_HIP_DEVICE -- there is no CPU fallback.
+ *
+ * Compiled with: hipcc -x hip --offload-arch=gfx950 -ffp-contract=off
+ * (tests/emu builds the same file with g++ -DPSD_EMU against the SIMT emulator).
+ */
+#include "../../include/peaksegdisk_hip.h"
+
+#include "fpop_kernels.h"
+
+#include <errno.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+namespace {
+
+thread_local std::string g_last_error;
+void (*g_print)(const char *) = nullptr;
+
+void set_error(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+void emit_text(const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (g_print) {
+    g_print(buf);
+  } else {
+    fputs(buf, stdout);
+  }
+}
+
+#define HIP_TRY(expr)                                                               \
+  do {                                                                              \
+    hipError_t e_ = (expr);                                                         \
+    if (e_ != hipSuccess) {                                                         \
+      set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return e_ == hipErrorOutOfMemory ? ERROR_DEVICE_MEMORY : ERROR_DEVICE_SOLVER; \
+    }                                                                               \
+  } while (0)
+
+/* ---- bedGraph input (drv:160-209) ---------------------------------------------------- */
+
+struct Coverage {
+  std::vector<int> chromEnd, count, weight;
+  std::string chrom; /* the last line's first column (drv:166,178) */
+  int first_chromStart = -1;
+  double cum_weight = 0.0, cum_weighted_count = 0.0;
+  double min_log_mean = INFINITY, max_log_mean = -INFINITY;
+  int n() const { return (int)count.size(); }
+};
+
+/* Pass 1 of the reference: same sscanf format, same checks in the same order. */
+int read_bedGraph(const char *path, Coverage &cv) {
+  FILE *f = fopen(path, "r");
+  if (!f) return ERROR_UNABLE_TO_OPEN_BEDGRAPH;
+  char *line = nullptr;
+  size_t cap = 0;
+  int chromStart, chromEnd = 0, coverage, items, line_i = 0;
+  char chrom[100];
+  char extra[100] = "";
+  int prev_chromEnd = -1;
+  int status = 0;
+  while (getline(&line, &cap, f) != -1) {
+    line_i++;
+    items = sscanf(line, "%s %d %d %d%s\n", chrom, &chromStart, &chromEnd, &coverage, extra);
+    if (items < 4) {
+      emit_text("problem: %d items on line %d\n", items, line_i);
+      status = ERROR_NOT_ENOUGH_COLUMNS;
+      break;
+    }
+    if (0 < strlen(extra)) {
+      status = ERROR_NON_INTEGER_DATA;
+      break;
+    }
+    double weight = chromEnd - chromStart;
+    cv.cum_weight += weight;
+    cv.cum_weighted_count += weight * coverage;
+    if (line_i == 1) {
+      cv.first_chromStart = chromStart;
+    } else if (chromStart != prev_chromEnd) {
+      status = ERROR_INCONSISTENT_CHROMSTART_CHROMEND;
+      break;
+    }
+    prev_chromEnd = chromEnd;
+    double log_data = psd_log((double)coverage);
+    if (log_data < cv.min_log_mean) cv.min_log_mean = log_data;
+    if (cv.max_log_mean < log_data) cv.max_log_mean = log_data;
+    cv.chromEnd.push_back(chromEnd);
+    cv.count.push_back(coverage);
+    cv.weight.push_back(chromEnd - chromStart);
+  }
+  free(line);
+  fclose(f);
+  if (status) return status;
+  if (line_i == 0) return ERROR_NO_DATA;
+  cv.chrom = chrom;
+  return 0;
+}
+
+/* penalty string handling of drv:145-159 */
+int parse_penalty(const char *s, bool &is_Inf, double &penalty) {
+  is_Inf = strcmp(s, "Inf") == 0;
+  char *end;
+  errno = 0;
+  penalty = strtod(s, &end);
+  if (end == s) return ERROR_PENALTY_NOT_NUMERIC;
+  if (is_Inf) return 0;
+  if (!std::isfinite(penalty)) return ERROR_PENALTY_NOT_FINITE;
+  if (penalty < 0) return ERROR_PENALTY_NEGATIVE;
+  return 0;
+}
+
+}  // namespace
+
+/* ---- device problem set --------------------------------------------------------------- */
+
+struct psd_problem_set {
+  int device = 0;
+  int n_contigs = 0, n_problems = 0;
+  std::vector<int> contig_n;
+  std::vector<long long> contig_off;
+  std::vector<int> prob_contig;
+  std::vector<double> prob_penalty;
+  std::vector<long long> prob_fn_off, prob_seg_off;
+  long long total_bins = 0, fn_total = 0, seg_total = 0;
+  unsigned long long arena_pieces = 0;
+  bool arena_auto = true;
+  psd::DeviceArgs d{};
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  std::vector<psd::ProbResult> results;
+  bool solved = false;
+  std::vector<void *> allocs;
+  unsigned long long bytes = 0;
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(psd_problem_set *s, T **p, size_t n) {
+  void *q = nullptr;
+  size_t bytes = (n ? n : 1) * sizeof(T);
+  hipError_t e = hipMalloc(&q, bytes);
+  if (e != hipSuccess) {
+    set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    return ERROR_DEVICE_MEMORY;
+  }
+  s->allocs.push_back(q);
+  s->bytes += bytes;
+  *p = (T *)q;
+  return 0;
+}
+
+template <class T>
+int dev_upload(psd_problem_set *s, const T **p, const std::vector<T> &v) {
+  T *q = nullptr;
+  int st = dev_alloc(s, &q, v.size());
+  if (st) return st;
+  if (!v.empty()) HIP_TRY(hipMemcpy(q, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *p = q;
+  return 0;
+}
+
+void free_arena(psd_problem_set *s) {
+  void *ptrs[3] = {s->d.ar_mx, s->d.ar_prv, s->d.ar_di};
+  for (void *q : ptrs) {
+    if (!q) continue;
+    for (size_t i = 0; i < s->allocs.size(); i++) {
+      if (s->allocs[i] == q) {
+        s->allocs.erase(s->allocs.begin() + (long)i);
+        break;
+      }
+    }
+    (void)hipFree(q);
+  }
+  s->bytes -= s->d.ar_cap * 20ull;
+  s->d.ar_mx = s->d.ar_prv = nullptr;
+  s->d.ar_di = nullptr;
+  s->d.ar_cap = 0;
+}
+
+int alloc_arena(psd_problem_set *s, unsigned long long pieces) {
+  /* whole chunks, and at least two per problem wave so that nobody starves at start-up */
+  unsigned long long min_pieces =
+      (unsigned long long)psd::ARENA_CHUNK * 2ull * (unsigned long long)s->n_problems;
+  if (pieces < min_pieces) pieces = min_pieces;
+  pieces = (pieces + psd::ARENA_CHUNK - 1) / psd::ARENA_CHUNK * psd::ARENA_CHUNK;
+  int st;
+  if ((st = dev_alloc(s, &s->d.ar_mx, pieces))) return st;
+  if ((st = dev_alloc(s, &s->d.ar_prv, pieces))) return st;
+  if ((st = dev_alloc(s, &s->d.ar_di, pieces))) return st;
+  s->d.ar_cap = pieces;
+  s->arena_pieces = pieces;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int peakseg_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" const char *peakseg_hip_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" void peakseg_hip_set_print(void (*print)(const char *)) { g_print = print; }
+
+extern "C" void peakseg_hip_problem_set_destroy(psd_problem_set *s) {
+  if (!s) return;
+  for (void *q : s->allocs) (void)hipFree(q);
+  for (auto &e : s->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+extern "C" unsigned long long peakseg_hip_problem_set_bytes(psd_problem_set *s) {
+  return s ? s->bytes : 0;
+}
+
+extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const int *contig_n_bins,
+                                              const int *const *contig_count,
+                                              const int *const *contig_weight, int n_problems,
+                                              const int *problem_contig,
+                                              const double *problem_penalty,
+                                              unsigned long long arena_pieces,
+                                              psd_problem_set **out) {
+  *out = nullptr;
+  if (peakseg_hip_device_count() <= device) {
+    set_error("no HIP device %d visible (this library has no CPU fallback)", device);
+    return ERROR_NO_HIP_DEVICE;
+  }
+  if (n_contigs <= 0 || n_problems <= 0) {
+    set_error("empty problem set");
+    return ERROR_DEVICE_SOLVER;
+  }
+  HIP_TRY(hipSetDevice(device));
+  psd_problem_set *s = new psd_problem_set();
+  s->device = device;
+  s->n_contigs = n_contigs;
+  s->n_problems = n_problems;
+  std::vector<int> count, weight;
+  std::vector<double> min_lm(n_contigs), max_lm(n_contigs);
+  long long off = 0;
+  for (int c = 0; c < n_contigs; c++) {
+    int n = contig_n_bins[c];
+    if (n <= 0 || n >= (1 << 30)) {
+      set_error("contig %d has %d bins", c, n);
+      delete s;
+      return ERROR_DEVICE_SOLVER;
+    }
+    s->contig_n.push_back(n);
+    s->contig_off.push_back(off);
+    off += n;
+    count.insert(count.end(), contig_count[c], contig_count[c] + n);
+    weight.insert(weight.end(), contig_weight[c], contig_weight[c] + n);
+    double mn = INFINITY, mx = -INFINITY;
+    for (int i = 0; i < n; i++) { /* drv:198-204 */
+      double log_data = psd_log((double)contig_count[c][i]);
+      if (log_data < mn) mn = log_data;
+      if (mx < log_data) mx = log_data;
+    }
+    min_lm[c] = mn;
+    max_lm[c] = mx;
+  }
+  s->total_bins = off;
+  long long fn_off = 0, seg_off = 0, dp_bins = 0;
+  for (int p = 0; p < n_problems; p++) {
+    int c = problem_contig[p];
+    if (c < 0 || c >= n_contigs) {
+      set_error("problem %d names contig %d", p, c);
+      delete s;
+      return ERROR_DEVICE_SOLVER;
+    }
+    s->prob_contig.push_back(c);
+    s->prob_penalty.push_back(problem_penalty[p]);
+    s->prob_fn_off.push_back(fn_off);
+    s->prob_seg_off.push_back(seg_off);
+    fn_off += 2ll * s->contig_n[c];
+    seg_off += s->contig_n[c] + 1;
+    dp_bins += s->contig_n[c];
+  }
+  s->fn_total = fn_off;
+  s->seg_total = seg_off;
+  int st = 0;
+  psd::DeviceArgs &d = s->d;
+  d.n_problems = n_problems;
+  if ((st = dev_upload(s, &d.prob_contig, s->prob_contig)) ||
+      (st = dev_upload(s, &d.prob_penalty, s->prob_penalty)) ||
+      (st = dev_upload(s, &d.prob_fn_off, s->prob_fn_off)) ||
+      (st = dev_upload(s, &d.prob_seg_off, s->prob_seg_off)) ||
+      (st = dev_upload(s, &d.contig_n, s->contig_n)) ||
+      (st = dev_upload(s, &d.contig_off, s->contig_off)) ||
+      (st = dev_upload(s, &d.contig_min_log_mean, min_lm)) ||
+      (st = dev_upload(s, &d.contig_max_log_mean, max_lm)) ||
+      (st = dev_upload(s, &d.count, count)) || (st = dev_upload(s, &d.weight, weight)) ||
+      (st = dev_alloc(s, &d.result, (size_t)n_problems)) ||
+      (st = dev_alloc(s, &d.ar_next_chunk, (size_t)1)) ||
+      (st = dev_alloc(s, &d.fn_ref, (size_t)fn_off)) ||
+      (st = dev_alloc(s, &d.seg_start, (size_t)seg_off)) ||
+      (st = dev_alloc(s, &d.seg_mean, (size_t)seg_off))) {
+    peakseg_hip_problem_set_destroy(s);
+    return st;
+  }
+  /* arena: the reference's store holds 2 functions per data point with, on typical
+   * coverage data, 2-14 pieces each; start at 24 per function and let
+   * solve() grow it if a problem reports PST_ARENA_FULL. */
+  s->arena_auto = arena_pieces == 0;
+  unsigned long long want = arena_pieces ? arena_pieces : (unsigned long long)dp_bins * 2ull * 24ull;
+  if (s->arena_auto) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      unsigned long long fit = (unsigned long long)(free_b * 0.9) / 20ull;
+      if (want > fit) want = fit;
+    }
+  }
+  if ((st = alloc_arena(s, want))) {
+    peakseg_hip_problem_set_destroy(s);
+    return st;
+  }
+  hipError_t e = hipStreamCreate(&s->stream);
+  for (auto &ev : s->ev)
+    if (e == hipSuccess) e = hipEventCreate(&ev);
+  if (e != hipSuccess) {
+    set_error("stream/event creation failed: %s", hipGetErrorString(e));
+    peakseg_hip_problem_set_destroy(s);
+    return ERROR_DEVICE_SOLVER;
+  }
+  s->results.resize((size_t)n_problems);
+  *out = s;
+  return 0;
+}
+
+extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_ms,
+                                             float *backtrack_ms) {
+  HIP_TRY(hipSetDevice(s->device));
+  for (int attempt = 0;; attempt++) {
+    HIP_TRY(hipMemsetAsync(s->d.ar_next_chunk, 0, sizeof(unsigned long long), s->stream));
+    HIP_TRY(hipEventRecord(s->ev[0], s->stream));
+    hipLaunchKernelGGL(psd::fpop_forward_kernel, dim3((unsigned)s->n_problems), dim3(128), 0,
+                       s->stream, s->d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev[1], s->stream));
+    hipLaunchKernelGGL(psd::fpop_backtrack_kernel, dim3((unsigned)s->n_problems), dim3(64), 0,
+                       s->stream, s->d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev[2], s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    float f_ms = 0.f, b_ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&f_ms, s->ev[0], s->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&b_ms, s->ev[1], s->ev[2]));
+    if (forward_ms) *forward_ms = f_ms;
+    if (backtrack_ms) *backtrack_ms = b_ms;
+    HIP_TRY(hipMemcpy(s->results.data(), s->d.result,
+                      sizeof(psd::ProbResult) * (size_t)s->n_problems, hipMemcpyDeviceToHost));
+    bool arena_full = false;
+    for (auto &r : s->results) arena_full = arena_full || r.status == psd::PST_ARENA_FULL;
+    if (!arena_full) break;
+    if (!s->arena_auto || attempt >= 4) {
+      set_error("cost-function arena of %llu pieces is too small", s->arena_pieces);
+      return ERROR_DEVICE_MEMORY;
+    }
+    /* grow and rerun the whole set */
+    unsigned long long bigger = s->arena_pieces * 3ull;
+    free_arena(s);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      unsigned long long fit = (unsigned long long)(free_b * 0.9) / 20ull;
+      if (bigger > fit) bigger = fit;
+    }
+    if (bigger <= s->arena_pieces) {
+      set_error("cost-function arena cannot grow beyond %llu pieces", s->arena_pieces);
+      return ERROR_DEVICE_MEMORY;
+    }
+    int st = alloc_arena(s, bigger);
+    if (st) return st;
+  }
+  s->solved = true;
+  int first = 0;
+  for (int p = 0; p < s->n_problems; p++) {
+    const psd::ProbResult &r = s->results[(size_t)p];
+    if (r.status != 0 && first == 0) {
+      set_error("problem %d: kernel status %d (wave error bits %d) at data point %d", p, r.status,
+                r.wave_err, r.step_reached);
+      first = ERROR_DEVICE_SOLVER;
+    }
+  }
+  return first;
+}
+
+extern "C" int peakseg_hip_problem_set_result(psd_problem_set *s, int p, psd_result *out) {
+  if (!s || !s->solved || p < 0 || p >= s->n_problems) return -1;
+  const psd::ProbResult &r = s->results[(size_t)p];
+  out->status = r.status == 0 ? 0 : ERROR_DEVICE_SOLVER;
+  out->kernel_status = r.status;
+  out->n_segments = r.n_segments;
+  out->n_peaks = (r.n_segments - 1) / 2;
+  out->n_equality_constraints = r.n_equality;
+  out->max_intervals = r.max_intervals;
+  out->total_intervals = r.total_intervals;
+  out->best_cost = r.best_cost;
+  out->n_serial_env = r.n_serial_env;
+  out->step_reached = r.step_reached;
+  return 0;
+}
+
+extern "C" int peakseg_hip_problem_set_segments(psd_problem_set *s, int p, int capacity,
+                                                int *seg_start, double *seg_mean) {
+  if (!s || !s->solved || p < 0 || p >= s->n_problems) return -1;
+  const psd::ProbResult &r = s->results[(size_t)p];
+  if (r.status != 0 || r.n_segments > capacity) return -1;
+  size_t n = (size_t)r.n_segments;
+  long long off = s->prob_seg_off[(size_t)p];
+  if (hipMemcpy(seg_start, s->d.seg_start + off, n * sizeof(int), hipMemcpyDeviceToHost) !=
+          hipSuccess ||
+      hipMemcpy(seg_mean, s->d.seg_mean + off, n * sizeof(double), hipMemcpyDeviceToHost) !=
+          hipSuccess) {
+    set_error("segment table download failed");
+    return -1;
+  }
+  return r.n_segments;
+}
+
+extern "C" int peakseg_hip_problem_set_export_db(psd_problem_set *s, int p, const int *chromEnd,
+                                                 const char *path) {
+  if (!s || !s->solved || p < 0 || p >= s->n_problems) return -1;
+  int N = s->contig_n[(size_t)s->prob_contig[(size_t)p]];
+  std::vector<unsigned long long> ref((size_t)2 * N);
+  if (hipMemcpy(ref.data(), s->d.fn_ref + s->prob_fn_off[(size_t)p], ref.size() * 8,
+                hipMemcpyDeviceToHost) != hipSuccess)
+    return -1;
+  FILE *f = fopen(path, "wb");
+  if (!f) return -1;
+  /* table of 2N std::streampos (16 bytes: offset + zero state), then records in the order
+   * the reference writes them: down_0, then (down_t, up_t) for t >= 1 (drv:388-392) */
+  std::vector<long long> table((size_t)4 * N, 0);
+  long long pos = 32ll * N;
+  std::vector<char> body;
+  std::vector<double> mx, prv;
+  std::vector<int> di;
+  for (int t = 0; t < N; t++) {
+    for (int which = 0; which < 2; which++) {
+      int element = which == 0 ? N + t : t;
+      if (which == 1 && t == 0) continue;
+      unsigned long long r = ref[(size_t)element];
+      unsigned long long off = r >> psd::FN_COUNT_BITS;
+      int n = (int)(r & ((1ull << psd::FN_COUNT_BITS) - 1));
+      mx.resize((size_t)n);
+      prv.resize((size_t)n);
+      di.resize((size_t)n);
+      if (hipMemcpy(mx.data(), s->d.ar_mx + off, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(prv.data(), s->d.ar_prv + off, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(di.data(), s->d.ar_di + off, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+        fclose(f);
+        return -1;
+      }
+      table[(size_t)2 * element] = pos;
+      int size = 20 * n + 8;
+      size_t at = body.size();
+      body.resize(at + 4 + (size_t)size);
+      char *q = body.data() + at;
+      memcpy(q, &size, 4);
+      q += 4;
+      memcpy(q, &n, 4);
+      q += 4;
+      memcpy(q, &chromEnd[t], 4);
+      q += 4;
+      for (int i = 0; i < n; i++) {
+        memcpy(q, &mx[(size_t)i], 8);
+        q += 8;
+        memcpy(q, &di[(size_t)i], 4);
+        q += 4;
+        memcpy(q, &prv[(size_t)i], 8);
+        q += 8;
+      }
+      pos += 4 + size;
+    }
+  }
+  bool ok = fwrite(table.data(), 8, table.size(), f) == table.size() &&
+            fwrite(body.data(), 1, body.size(), f) == body.size();
+  ok = fclose(f) == 0 && ok;
+  return ok ? 0 : -1;
+}
+
+extern "C" int peakseg_hip_math_probe(int op, int n, const double *x, double *y) {
+  if (peakseg_hip_device_count() <= 0) {
+    set_error("no HIP device visible (this library has no CPU fallback)");
+    return ERROR_NO_HIP_DEVICE;
+  }
+  if (n <= 0) return 0;
+  double *dx = nullptr, *dy = nullptr;
+  HIP_TRY(hipMalloc(&dx, (size_t)n * 8));
+  HIP_TRY(hipMalloc(&dy, (size_t)n * 8));
+  HIP_TRY(hipMemcpy(dx, x, (size_t)n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(psd::math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t) nullptr, op, n, dx, dy);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(y, dy, (size_t)n * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(dx);
+  (void)hipFree(dy);
+  return 0;
+}
+
+/* ---- file-level solver (the reference's boundary) ------------------------------------- */
+
+namespace {
+
+struct FileProblem {
+  const char *bedGraph, *penalty_str, *db;
+  int status = 0;
+  bool is_Inf = false;
+  double penalty = 0.0;
+  int cov = -1;     /* index into the parsed-coverage table */
+  int dp_index = -1; /* index into the device problem set, -1 = trivial/none */
+  FILE *loss_file = nullptr, *segments_file = nullptr;
+  bool loss_failed = false, segments_failed = false;
+};
+
+void out_printf(FILE *f, bool &failed, const char *fmt, ...) {
+  if (!f) return;
+  va_list ap;
+  va_start(ap, fmt);
+  if (vfprintf(f, fmt, ap) < 0) failed = true;
+  va_end(ap);
+}
+
+void close_outputs(FileProblem &fp) {
+  if (fp.loss_file) {
+    if (fclose(fp.loss_file) != 0) fp.loss_failed = true;
+    fp.loss_file = nullptr;
+  }
+  if (fp.segments_file) {
+    if (fclose(fp.segments_file) != 0) fp.segments_failed = true;
+    fp.segments_file = nullptr;
+  }
+}
+
+/* trivial one-segment model (drv:224-243) */
+void write_trivial(FileProblem &fp, const Coverage &cv) {
+  double best_cost;
+  if (cv.cum_weighted_count != 0) {
+    best_cost =
+        cv.cum_weighted_count * (1 - psd_log(cv.cum_weighted_count) + psd_log(cv.cum_weight));
+  } else {
+    best_cost = 0;
+  }
+  out_printf(fp.segments_file, fp.segments_failed, "%s\t%d\t%d\tbackground\t%g\n",
+             cv.chrom.c_str(), cv.first_chromStart, cv.chromEnd.back(),
+             cv.cum_weighted_count / cv.cum_weight);
+  out_printf(fp.loss_file, fp.loss_failed, "%s\t%d\t%d\t%d\t%d\t%.20g\t%.20g\t%d\t%d\t%d\n",
+             fp.penalty_str, 1, 0, (int)cv.cum_weight, cv.n(), best_cost / cv.cum_weight, best_cost,
+             0, 0, 0);
+}
+
+/* the DP branch's two files (drv:419-454) from the device results */
+int write_dp_outputs(FileProblem &fp, const Coverage &cv, psd_problem_set *set) {
+  psd_result r;
+  if (peakseg_hip_problem_set_result(set, fp.dp_index, &r) != 0 || r.status != 0)
+    return ERROR_DEVICE_SOLVER;
+  std::vector<int> seg_start((size_t)r.n_segments);
+  std::vector<double> seg_mean((size_t)r.n_segments);
+  if (peakseg_hip_problem_set_segments(set, fp.dp_index, r.n_segments, seg_start.data(),
+                                       seg_mean.data()) != r.n_segments)
+    return ERROR_DEVICE_SOLVER;
+  int prev_chromEnd = cv.chromEnd.back();
+  const char *chrom = cv.chrom.c_str();
+  for (int row = 0; row < r.n_segments; row++) {
+    int start = seg_start[(size_t)row] < 0 ? cv.first_chromStart
+                                           : cv.chromEnd[(size_t)seg_start[(size_t)row]];
+    /* rows alternate background/peak starting and ending with background (drv:421-429,442) */
+    const char *status_str = (row % 2 == 0) ? "background" : "peak";
+    out_printf(fp.segments_file, fp.segments_failed, "%s\t%d\t%d\t%s\t%g\n", chrom, start,
+               prev_chromEnd, status_str, seg_mean[(size_t)row]);
+    prev_chromEnd = start;
+  }
+  int n_peaks = (r.n_segments - 1) / 2;
+  double total_intervals = (double)r.total_intervals;
+  out_printf(fp.loss_file, fp.loss_failed,
+             "%.20g\t%d\t%d\t%d\t%d\t%.20g\t%.20g\t%d\t%.20g\t%.20g\n", fp.penalty,
+             r.n_segments, n_peaks, (int)cv.cum_weight, cv.n(), r.best_cost,
+             r.best_cost * cv.cum_weight - fp.penalty * n_peaks, r.n_equality_constraints,
+             total_intervals / (cv.n() * 2), (double)r.max_intervals);
+  /* leave a sparse file of the size the reference's DiskVector would have:
+   * 2N 16-byte positions + per function {int size, int n, int chromEnd} + 20 B per piece */
+  long long db_size = 32ll * cv.n() + 12ll * (2ll * cv.n() - 1) + 20ll * (long long)r.total_intervals;
+  if (truncate(fp.db, (off_t)db_size) != 0) return ERROR_WRITING_COST_FUNCTIONS;
+  return 0;
+}
+
+int solve_files(int n, FileProblem *fps) {
+  std::vector<Coverage> covs;
+  std::map<std::string, int> cov_of_path;
+  std::map<std::string, int> cov_status;
+  /* 1. penalties, then inputs (validation order of drv:145-209) */
+  for (int i = 0; i < n; i++) {
+    FileProblem &fp = fps[i];
+    fp.status = parse_penalty(fp.penalty_str, fp.is_Inf, fp.penalty);
+    if (fp.status) continue;
+    std::string path = fp.bedGraph;
+    auto it = cov_of_path.find(path);
+    if (it == cov_of_path.end()) {
+      Coverage cv;
+      int st = read_bedGraph(fp.bedGraph, cv);
+      covs.push_back(std::move(cv));
+      int idx = (int)covs.size() - 1;
+      cov_of_path[path] = idx;
+      cov_status[path] = st;
+      it = cov_of_path.find(path);
+    }
+    fp.cov = it->second;
+    fp.status = cov_status[path];
+  }
+  /* 2. output files are opened before the trivial/DP split (drv:212-223); the db is only
+   *    touched in the DP branch (drv:247-252) */
+  std::vector<int> dp;
+  for (int i = 0; i < n; i++) {
+    FileProblem &fp = fps[i];
+    if (fp.status) continue;
+    const Coverage &cv = covs[(size_t)fp.cov];
+    std::string pre = std::string(fp.bedGraph) + "_penalty=" + fp.penalty_str;
+    fp.loss_file = fopen((pre + "_loss.tsv").c_str(), "w");
+    fp.segments_file = fopen((pre + "_segments.bed").c_str(), "w");
+    fp.loss_failed = fp.loss_file == nullptr;
+    fp.segments_failed = fp.segments_file == nullptr;
+    if (fp.is_Inf || cv.min_log_mean == cv.max_log_mean) {
+      write_trivial(fp, cv);
+    } else {
+      FILE *db = fopen(fp.db, "w+b");
+      if (!db) {
+        fp.status = ERROR_WRITING_COST_FUNCTIONS;
+        close_outputs(fp);
+        continue;
+      }
+      fclose(db);
+      dp.push_back(i);
+    }
+  }
+  /* 3. all dynamic programs in one device problem set */
+  if (!dp.empty()) {
+    std::vector<int> used_cov, contig_of_cov(covs.size(), -1);
+    std::vector<int> contig_n, prob_contig;
+    std::vector<const int *> cnt_ptr, wt_ptr;
+    std::vector<double> prob_pen;
+    for (int i : dp) {
+      FileProblem &fp = fps[i];
+      if (contig_of_cov[(size_t)fp.cov] < 0) {
+        contig_of_cov[(size_t)fp.cov] = (int)contig_n.size();
+        const Coverage &cv = covs[(size_t)fp.cov];
+        contig_n.push_back(cv.n());
+        cnt_ptr.push_back(cv.count.data());
+        wt_ptr.push_back(cv.weight.data());
+      }
+      fp.dp_index = (int)prob_contig.size();
+      prob_contig.push_back(contig_of_cov[(size_t)fp.cov]);
+      prob_pen.push_back(fp.penalty);
+    }
+    psd_problem_set *set = nullptr;
+    int st = peakseg_hip_problem_set_create(0, (int)contig_n.size(), contig_n.data(),
+                                            cnt_ptr.data(), wt_ptr.data(), (int)prob_contig.size(),
+                                            prob_contig.data(), prob_pen.data(), 0, &set);
+    if (st == 0) {
+      st = peakseg_hip_problem_set_solve(set, nullptr, nullptr);
+      if (st == ERROR_DEVICE_SOLVER) st = 0; /* per-problem statuses decide below */
+    }
+    for (int i : dp) {
+      FileProblem &fp = fps[i];
+      if (st) {
+        fp.status = st;
+      } else {
+        fp.status = write_dp_outputs(fp, covs[(size_t)fp.cov], set);
+      }
+    }
+    peakseg_hip_problem_set_destroy(set);
+  }
+  /* 4. close, report write failures (drv:456-461: loss first) */
+  int first = 0;
+  for (int i = 0; i < n; i++) {
+    FileProblem &fp = fps[i];
+    bool had_outputs = fp.loss_file || fp.segments_file || fp.loss_failed || fp.segments_failed;
+    close_outputs(fp);
+    if (fp.status == 0 && had_outputs) {
+      if (fp.loss_failed) {
+        fp.status = ERROR_WRITING_LOSS_OUTPUT;
+      } else if (fp.segments_failed) {
+        fp.status = ERROR_WRITING_SEGMENTS_OUTPUT;
+      }
+    }
+    if (fp.status && !first) first = fp.status;
+  }
+  return first;
+}
+
+}  // namespace
+
+extern "C" int PeakSegFPOP_disk(char *bedGraph_file_name, char *penalty_str, char *db_file_name) {
+  FileProblem fp;
+  fp.bedGraph = bedGraph_file_name;
+  fp.penalty_str = penalty_str;
+  fp.db = db_file_name;
+  return solve_files(1, &fp);
+}
+
+extern "C" int PeakSegFPOP_disk_batch(int n_problems, char **bedGraph_files, char **penalty_strs,
+                                      char **db_files, int *status_out) {
+  if (n_problems <= 0) return 0;
+  std::vector<FileProblem> fps((size_t)n_problems);
+  for (int i = 0; i < n_problems; i++) {
+    fps[(size_t)i].bedGraph = bedGraph_files[i];
+    fps[(size_t)i].penalty_str = penalty_strs[i];
+    fps[(size_t)i].db = db_files[i];
+  }
+  int first = solve_files(n_problems, fps.data());
+  if (status_out)
+    for (int i = 0; i < n_problems; i++) status_out[i] = fps[(size_t)i].status;
+  return first;
+}
+
+extern "C" char *PeakSegFPOP_status_message(int status, const char *bedGraph, const char *penalty,
+                                            const char *db, char *buf, size_t buf_len) {
+  if (!buf || buf_len == 0) return buf;
+  buf[0] = 0;
+  switch (status) { /* texts of /root/reference/src/interface.cpp:16-55 */
+    case 0:
+      break;
+    case ERROR_PENALTY_NOT_FINITE:
+      snprintf(buf, buf_len, "penalty=%s but must be finite", penalty);
+      break;
+    case ERROR_PENALTY_NEGATIVE:
+      snprintf(buf, buf_len, "penalty=%s must be non-negative", penalty);
+      break;
+    case ERROR_UNABLE_TO_OPEN_BEDGRAPH:
+      snprintf(buf, buf_len, "unable to open input file for reading %s", bedGraph);
+      break;
+    case ERROR_NOT_ENOUGH_COLUMNS:
+      snprintf(buf, buf_len, "each line of input data file %s should have exactly four columns",
+               bedGraph);
+      break;
+    case ERROR_NON_INTEGER_DATA:
+      snprintf(buf, buf_len, "fourth column of input data file %s should be integer", bedGraph);
+      break;
+    case ERROR_INCONSISTENT_CHROMSTART_CHROMEND:
+      snprintf(buf, buf_len, "there should be no gaps (columns 2-3) in input data file %s",
+               bedGraph);
+      break;
+    case ERROR_WRITING_COST_FUNCTIONS:
+      snprintf(buf, buf_len, "unable to write to cost function database file %s", db);
+      break;
+    case ERROR_WRITING_LOSS_OUTPUT:
+      snprintf(buf, buf_len, "unable to write to loss output file %s_penalty=%s_loss.tsv", bedGraph,
+               penalty);
+      break;
+    case ERROR_WRITING_SEGMENTS_OUTPUT:
+      snprintf(buf, buf_len, "unable to write to segments output file %s_penalty=%s_segments.bed",
+               bedGraph, penalty);
+      break;
+    case ERROR_NO_DATA:
+      snprintf(buf, buf_len, "input file %s contains no data", bedGraph);
+      break;
+    case ERROR_PENALTY_NOT_NUMERIC:
+      snprintf(buf, buf_len,
+               "penalty string '%s' is not numeric; it should be convertible to double", penalty);
+      break;
+    case ERROR_NO_HIP_DEVICE:
+      snprintf(buf, buf_len,
+               "error code %d: no HIP device (MI355X) is visible and this solver has no CPU path",
+               status);
+      break;
+    default:
+      snprintf(buf, buf_len, "error code %d", status);
+      break;
+  }
+  return buf;
+}

@@ -1,0 +1,70 @@
+/* psd_platform.h -- the (small) set of HIP device features the kernels use.
+ *
+ * Product build: hipcc --offload-arch=gfx950, real intrinsics.
+ * Test build (-DPSD_EMU, tests/emu/ only): the same kernel source compiled by g++ against
+ * tests/emu/hip_emu.h, a fiber-based SIMT emulator used to debug kernel logic without a
+ * GPU.  The emulator is never built into or loaded by the product library.
+ *
+ * Rules the kernels follow so both builds mean the same thing:
+ *   - wavefront = 64 lanes, hard-coded;
+ *   - every cross-lane operation (ballot/shfl/wave_sync) and __syncthreads() is reached in
+ *     wave-uniform (resp. block-uniform) control flow by ALL lanes;
+ *   - lanes of a wave exchange data through LDS only across a wave_sync().
+ */
+#ifndef PSD_PLATFORM_H
+#define PSD_PLATFORM_H
+
+#ifdef PSD_EMU
+#include "hip_emu.h"
+#define PSD_D static inline
+#else
+#include <hip/hip_runtime.h>
+#define PSD_D __device__ __forceinline__
+#endif
+
+#include "peakseg_detmath.h"
+
+namespace psd {
+
+constexpr int WAVE = 64;
+
+PSD_D int lane_id() { return (int)(threadIdx.x & 63u); }
+PSD_D int wave_id() { return (int)(threadIdx.x >> 6); }
+
+#ifdef PSD_EMU
+PSD_D unsigned long long ballot(bool p) { return emu::ballot(p); }
+PSD_D double shfl_d(double v, int src) { return emu::shfl_f64(v, src); }
+PSD_D int shfl_i(int v, int src) { return emu::shfl_i32(v, src); }
+PSD_D void wave_sync() { emu::wave_sync(); }
+PSD_D int uniform_i(int v) { return v; }
+PSD_D double uniform_d(double v) { return v; }
+#else
+PSD_D unsigned long long ballot(bool p) { return __ballot(p); }
+PSD_D double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+PSD_D int shfl_i(int v, int src) { return __shfl(v, src, 64); }
+/* Lanes of one wave execute LDS instructions in order; the fences keep the compiler from
+ * moving this lane's LDS accesses across the point where it relies on another lane's. */
+PSD_D void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+/* tell the compiler a value is wave-uniform (keeps it in SGPRs) */
+PSD_D int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+PSD_D double uniform_d(double v) {
+  uint64_t u = psd_d2u(v);
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+  return psd_u2d(((uint64_t)hi << 32) | lo);
+}
+#endif
+
+PSD_D int popc64(unsigned long long m) { return __builtin_popcountll(m); }
+/* index of the lowest set bit; m != 0 */
+PSD_D int ctz64(unsigned long long m) { return __builtin_ctzll(m); }
+/* index of the highest set bit; m != 0 */
+PSD_D int msb64(unsigned long long m) { return 63 - __builtin_clzll(m); }
+PSD_D unsigned long long lanes_below(int lane) { return (1ull << lane) - 1ull; }
+
+}  // namespace psd
+#endif

@@ -1,0 +1,81 @@
+"""Device-resident (penalty x contig) problem sets: the additive grid entry of the C ABI
+(include/peaksegdisk_hip.h, peakseg_hip_problem_set_*).  One problem = one dynamic program
+of /root/reference/src/PeakSegFPOPLog.cpp:258-442 for a (contig, penalty) pair."""
+import ctypes
+
+import numpy as np
+
+from . import _native
+
+
+class ProblemSet:
+    """contigs: list of (count, weight) int32 arrays; problems: list of (contig_index, penalty)."""
+
+    def __init__(self, contigs, problems, device=0, arena_pieces=0, lib=None):
+        self._lib = lib or _native.lib
+        self._h = ctypes.c_void_p()
+        self.contigs = [(np.ascontiguousarray(c, dtype=np.int32),
+                         np.ascontiguousarray(w, dtype=np.int32)) for c, w in contigs]
+        self.problems = [(int(c), float(p)) for c, p in problems]
+        nc = len(self.contigs)
+        n_bins = (ctypes.c_int * nc)(*[len(c) for c, _ in self.contigs])
+        cptr = (ctypes.c_void_p * nc)(*[c.ctypes.data for c, _ in self.contigs])
+        wptr = (ctypes.c_void_p * nc)(*[w.ctypes.data for _, w in self.contigs])
+        npb = len(self.problems)
+        pc = (ctypes.c_int * npb)(*[c for c, _ in self.problems])
+        pp = (ctypes.c_double * npb)(*[p for _, p in self.problems])
+        st = self._lib.peakseg_hip_problem_set_create(
+            device, nc, n_bins, cptr, wptr, npb, pc, pp, ctypes.c_ulonglong(arena_pieces),
+            ctypes.byref(self._h))
+        if st != 0:
+            raise RuntimeError("peakseg_hip_problem_set_create: status %d: %s" % (
+                st, self._lib.peakseg_hip_last_error().decode()))
+        self.bins_per_solve = sum(len(self.contigs[c][0]) for c, _ in self.problems)
+
+    def solve(self):
+        """Forward DP + backtrack for every problem; returns (forward_ms, backtrack_ms)."""
+        f = ctypes.c_float()
+        b = ctypes.c_float()
+        st = self._lib.peakseg_hip_problem_set_solve(self._h, ctypes.byref(f), ctypes.byref(b))
+        if st != 0:
+            raise RuntimeError("peakseg_hip_problem_set_solve: status %d: %s" % (
+                st, self._lib.peakseg_hip_last_error().decode()))
+        return f.value, b.value
+
+    def result(self, p):
+        r = _native.PsdResult()
+        if self._lib.peakseg_hip_problem_set_result(self._h, p, ctypes.byref(r)) != 0:
+            raise RuntimeError("no result for problem %d" % p)
+        return r
+
+    def segments(self, p):
+        """(seg_start_index, seg_mean) in the reference's output order (last segment first)."""
+        r = self.result(p)
+        start = np.empty(max(r.n_segments, 1), dtype=np.int32)
+        mean = np.empty(max(r.n_segments, 1), dtype=np.float64)
+        n = self._lib.peakseg_hip_problem_set_segments(
+            self._h, p, r.n_segments, start.ctypes.data, mean.ctypes.data)
+        if n < 0:
+            raise RuntimeError("segments(%d): %s" % (p, self._lib.peakseg_hip_last_error().decode()))
+        return start[:n], mean[:n]
+
+    def export_db(self, p, chrom_end, path):
+        ce = np.ascontiguousarray(chrom_end, dtype=np.int32)
+        if self._lib.peakseg_hip_problem_set_export_db(self._h, p, ce.ctypes.data,
+                                                       path.encode()) != 0:
+            raise RuntimeError("export_db failed")
+
+    @property
+    def hbm_bytes(self):
+        return int(self._lib.peakseg_hip_problem_set_bytes(self._h))
+
+    def close(self):
+        if self._h:
+            self._lib.peakseg_hip_problem_set_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,59 @@
+"""CPU rehearsal of the GPU parity tests: the product's host driver + kernel SOURCE compiled
+against the SIMT emulator in tests/emu (test infrastructure), checked against the oracle.
+
+This exercises kernel logic, the C ABI, the host driver and the Python entry points without a
+GPU.  It proves nothing about the real hardware build -- tests/test_gpu_parity.py does that
+on an MI355X -- and the emulator library is never loaded by the product package: this module
+swaps it into peaksegdisk_amd._native for the duration of its own tests only."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+import test_gpu_parity as gp
+from conftest import ROOT
+
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+
+
+@pytest.fixture(scope="module")
+def psd():
+    import __graft_entry__ as entry
+    entry.build_hip()  # the package refuses to import without its HIP library
+    subprocess.run(["make", "-s", "-C", EMU_DIR], check=True)
+    import peaksegdisk_amd
+    from peaksegdisk_amd import _native
+    emu = _native.declare(ctypes.CDLL(os.path.join(EMU_DIR, "_build", "libpeaksegdisk_emu.so")))
+    real = _native.lib
+    _native.lib = emu
+    try:
+        yield peaksegdisk_amd
+    finally:
+        _native.lib = real
+
+
+def test_emu_known_answers(psd, oracle_det, known_answers, tmp_path):
+    gp.test_known_answers_byte_identical(psd, oracle_det, known_answers, tmp_path)
+
+
+def test_emu_error_cases(psd, known_answers, tmp_path):
+    gp.test_error_cases(psd, known_answers, tmp_path)
+
+
+def test_emu_mono27ac(psd, oracle_det, oracle_libm, known_answers, tmp_path, monkeypatch):
+    monkeypatch.setattr(gp, "MONO_PENALTIES", ["1952.6", "Inf", "157.994737329317"])
+    gp.test_mono27ac_files_and_store_identical(psd, oracle_det, oracle_libm, known_answers,
+                                               tmp_path)
+
+
+def test_emu_arena_equals_oracle_db(psd, oracle_det, tmp_path):
+    gp.test_arena_equals_oracle_db(psd, oracle_det, tmp_path)
+
+
+def test_emu_synthetic(psd, oracle_det, oracle_libm, tmp_path):
+    gp.test_synthetic_grid_vs_oracle(psd, oracle_det, oracle_libm, tmp_path, 1500, 12)
+
+
+def test_emu_python_entry_points(psd, tmp_path):
+    gp.test_python_entry_points(psd, tmp_path)

@@ -1,0 +1,208 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on an
+MI355X.  Integer fields, segment rows and whole output files must be bit/byte identical to
+oracle/_build/liboracle_det.so (same deterministic exp/log); against the libm build --
+the arithmetic the reference itself uses -- endpoints/states must be identical and the
+Poisson loss within 1e-6 relative (BASELINE.json north_star)."""
+import ctypes
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, read_loss, read_segments
+
+GPU = pytest.mark.gpu
+REL_TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def psd():
+    import __graft_entry__ as entry
+    entry.build_hip()
+    import peaksegdisk_amd
+    from peaksegdisk_amd import _native
+    assert _native.lib.peakseg_hip_device_count() >= 1, "no HIP device: GPU tests need an MI355X"
+    return peaksegdisk_amd
+
+
+def _solve_hip(psd, bg, pen, db=None):
+    from peaksegdisk_amd import _native
+    if db is None:
+        db = "%s_penalty=%s.db" % (bg, pen)
+    return _native.lib.PeakSegFPOP_disk(os.fsencode(bg), pen.encode(), os.fsencode(db))
+
+
+def _files(bg, pen):
+    pre = "%s_penalty=%s" % (bg, pen)
+    return open(pre + "_segments.bed", "rb").read(), open(pre + "_loss.tsv", "rb").read()
+
+
+@GPU
+def test_device_math_is_bit_identical_to_host(psd, oracle_det):
+    from peaksegdisk_amd import _native
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.uniform(-30, 30, 200000), rng.uniform(-745, 709, 50000),
+                         rng.uniform(-1e-5, 1e-5, 10000),
+                         np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 709.78, -745.1, 1e-320])])
+    pos = np.concatenate([rng.uniform(0, 100, 200000), np.exp(rng.uniform(-700, 700, 50000)),
+                          1 + rng.uniform(-1e-3, 1e-3, 10000),
+                          np.array([0.0, 1.0, np.inf, -1.0, np.nan, 5e-324, 2.2e-308])])
+    for op, x in ((0, xs), (1, pos)):
+        x = np.ascontiguousarray(x)
+        y = np.empty_like(x)
+        assert _native.lib.peakseg_hip_math_probe(op, x.size, x.ctypes.data, y.ctypes.data) == 0
+        want = oracle_det.math("exp" if op == 0 else "log", x)
+        assert np.array_equal(y.view(np.uint64), want.view(np.uint64))
+
+
+@GPU
+def test_known_answers_byte_identical(psd, oracle_det, known_answers, tmp_path):
+    for i, case in enumerate(known_answers["solve_cases"]):
+        g = tmp_path / ("g%d" % i)
+        o = tmp_path / ("o%d" % i)
+        g.mkdir()
+        o.mkdir()
+        gb, ob = str(g / "coverage.bedGraph"), str(o / "coverage.bedGraph")
+        open(gb, "w").write(case["bedGraph"])
+        open(ob, "w").write(case["bedGraph"])
+        assert _solve_hip(psd, gb, case["penalty"]) == case["status"], case["name"]
+        assert oracle_det.solve(ob, case["penalty"]) == case["status"]
+        assert _files(gb, case["penalty"]) == _files(ob, case["penalty"]), case["name"]
+        if "segments" in case:
+            segs = read_segments("%s_penalty=%s_segments.bed" % (gb, case["penalty"]))
+            assert segs == [list(r) for r in case["segments"]]
+        if "db_bytes" in case:
+            assert os.path.getsize(gb + "_penalty=%s.db" % case["penalty"]) == case["db_bytes"]
+
+
+@GPU
+def test_error_cases(psd, known_answers, tmp_path):
+    from peaksegdisk_amd import _native
+    for i, case in enumerate(known_answers["error_cases"]):
+        d = tmp_path / ("e%d" % i)
+        d.mkdir()
+        bg = str(d / "missing") if case["bedGraph"] is None else str(d / "coverage.bedGraph")
+        if case["bedGraph"] is not None:
+            open(bg, "w").write(case["bedGraph"])
+        pre = "%s_penalty=%s" % (bg, case["penalty"])
+        db = pre + ".db"
+        if case.get("block") == "segments":
+            os.mkdir(pre + "_segments.bed")
+        elif case.get("block") == "loss":
+            os.mkdir(pre + "_loss.tsv")
+        elif case.get("block") == "db":
+            os.mkdir(db)
+        st = _solve_hip(psd, bg, case["penalty"], db)
+        assert st == case["status"], case["name"]
+        assert case["message"] in _native.status_message(st, bg, case["penalty"], db)
+
+
+MONO_PENALTIES = ["1952.6", "0", "10000", "Inf", "157.994737329317", "1952.66876946418",
+                  "313.236999786254", "605.365673153523", "1094.30971435653", "1548.04195002439",
+                  "1752.96395944988", "1694.47781380514", "1715.84956360692"]
+
+
+@GPU
+def test_mono27ac_files_and_store_identical(psd, oracle_det, oracle_libm, known_answers, tmp_path):
+    from peaksegdisk_amd import _native
+    dirs = {}
+    for name in ("gpu", "det", "libm"):
+        d = tmp_path / name
+        d.mkdir()
+        shutil.copy(os.path.join(GOLDEN, "Mono27ac.bedGraph"), str(d / "coverage.bedGraph"))
+        dirs[name] = str(d / "coverage.bedGraph")
+    n = len(MONO_PENALTIES)
+    arr = lambda xs: (ctypes.c_char_p * n)(*[x.encode() for x in xs])
+    status = (ctypes.c_int * n)()
+    st = _native.lib.PeakSegFPOP_disk_batch(
+        n, arr([dirs["gpu"]] * n), arr(MONO_PENALTIES),
+        arr(["%s_penalty=%s.db" % (dirs["gpu"], p) for p in MONO_PENALTIES]), status)
+    assert st == 0 and list(status) == [0] * n, _native.last_error()
+    want_peaks = dict(zip(known_answers["mono27ac"]["sequential_search_19"]["penalties"],
+                          known_answers["mono27ac"]["sequential_search_19"]["peaks"]))
+    for pen in MONO_PENALTIES:
+        assert oracle_det.solve(dirs["det"], pen) == 0
+        assert oracle_libm.solve(dirs["libm"], pen) == 0
+        g_seg, g_loss = _files(dirs["gpu"], pen)
+        assert (g_seg, g_loss) == _files(dirs["det"], pen), pen
+        l_seg, l_loss = _files(dirs["libm"], pen)
+        assert g_seg == l_seg, pen  # endpoints, states, 6-digit means vs the libm arithmetic
+        gl, ll = g_loss.decode().split("\t"), l_loss.decode().split("\t")
+        assert gl[1:5] == ll[1:5] and gl[7] == ll[7]
+        assert float(gl[6]) == pytest.approx(float(ll[6]), rel=REL_TOL)
+        if pen in want_peaks:
+            assert int(gl[2]) == want_peaks[pen]
+        if pen != "Inf":  # sparse db file has the size of the reference's store
+            assert os.path.getsize("%s_penalty=%s.db" % (dirs["gpu"], pen)) == \
+                os.path.getsize("%s_penalty=%s.db" % (dirs["det"], pen))
+
+
+@GPU
+def test_arena_equals_oracle_db(psd, oracle_det, tmp_path):
+    """Every stored function (max_log_mean, data_i, prev_log_mean per piece, for both chains
+    and every data point) equals the oracle's DiskVector file byte for byte."""
+    from peaksegdisk_amd import ProblemSet
+    cov = np.loadtxt(os.path.join(GOLDEN, "Mono27ac.bedGraph"), usecols=(1, 2, 3), dtype=np.int64)
+    cs, ce, cnt = cov[:, 0], cov[:, 1], cov[:, 2]
+    pens = ["1952.6", "0.5", "31.7"]
+    pset = ProblemSet([(cnt.astype(np.int32), (ce - cs).astype(np.int32))],
+                      [(0, float(p)) for p in pens])
+    pset.solve()
+    bg = str(tmp_path / "coverage.bedGraph")
+    shutil.copy(os.path.join(GOLDEN, "Mono27ac.bedGraph"), bg)
+    for i, pen in enumerate(pens):
+        db_o = str(tmp_path / ("oracle_%d.db" % i))
+        assert oracle_det.solve(bg, pen, db_o) == 0
+        db_g = str(tmp_path / ("gpu_%d.db" % i))
+        pset.export_db(i, ce, db_g)
+        assert open(db_g, "rb").read() == open(db_o, "rb").read(), pen
+    pset.close()
+
+
+@GPU
+@pytest.mark.parametrize("n_bins,seed", [(20000, 11), (3000, 12)])
+def test_synthetic_grid_vs_oracle(psd, oracle_det, oracle_libm, tmp_path, n_bins, seed):
+    from peaksegdisk_amd import _native, synthetic
+    cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=seed)
+    pens = synthetic.penalty_grid(16)
+    paths = {}
+    for name in ("gpu", "det", "libm"):
+        d = tmp_path / name
+        d.mkdir()
+        paths[name] = str(d / "coverage.bedGraph")
+        synthetic.write_bedgraph(paths[name], cs, ce, cnt)
+    n = len(pens)
+    arr = lambda xs: (ctypes.c_char_p * n)(*[x.encode() for x in xs])
+    status = (ctypes.c_int * n)()
+    st = _native.lib.PeakSegFPOP_disk_batch(
+        n, arr([paths["gpu"]] * n), arr(pens),
+        arr(["%s_penalty=%s.db" % (paths["gpu"], p) for p in pens]), status)
+    assert st == 0 and list(status) == [0] * n, _native.last_error()
+    for pen in pens:
+        assert oracle_det.solve(paths["det"], pen) == 0
+        assert _files(paths["gpu"], pen) == _files(paths["det"], pen), pen
+    for pen in pens[::5]:
+        assert oracle_libm.solve(paths["libm"], pen) == 0
+        g_seg, g_loss = _files(paths["gpu"], pen)
+        l_seg, l_loss = _files(paths["libm"], pen)
+        assert g_seg == l_seg
+        assert float(g_loss.split(b"\t")[6]) == pytest.approx(float(l_loss.split(b"\t")[6]),
+                                                              rel=REL_TOL)
+
+
+@GPU
+def test_python_entry_points(psd, tmp_path):
+    """PeakSegFPOP_vec / _df / _dir / sequentialSearch_dir through the HIP library, with the
+    reference tests' expectations (test-CRAN-PeakSegFPOP_vec.R, test-TRAVIS-sequentialSearch.R)."""
+    fit_inf = psd.PeakSegFPOP_vec(np.array([1, 3, 0, 4, 2], dtype=np.int32), float("inf"))
+    assert len(fit_inf.segments) == 1
+    fit0 = psd.PeakSegFPOP_vec(np.array([1, 3, 0, 4, 2], dtype=np.int32), 0)
+    assert len(fit0.segments) == 5
+    d = tmp_path / "chr11-60000-580000"
+    d.mkdir()
+    shutil.copy(os.path.join(GOLDEN, "Mono27ac.bedGraph"), str(d / "coverage.bedGraph"))
+    fit = psd.sequentialSearch_dir(str(d), 19)
+    assert int(fit.loss["peaks"].iloc[0]) == 19
+    assert list(fit.others["peaks"]) == [3199, 0, 224, 17, 74, 35, 25, 21, 18, 20, 19] or \
+        sorted(fit.others["peaks"]) == sorted([3199, 0, 224, 17, 74, 35, 25, 21, 18, 20, 19])
