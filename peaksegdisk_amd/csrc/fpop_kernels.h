@@ -26,7 +26,6 @@
 
 namespace psd {
 
-constexpr int LDS_CAP = 128;          /* pieces per LDS-resident list */
 constexpr int ARENA_CHUNK_LOG2 = 16;  /* arena is handed out in chunks of 65536 pieces */
 constexpr int ARENA_CHUNK = 1 << ARENA_CHUNK_LOG2;
 constexpr int FN_COUNT_BITS = 24;     /* fn_ref = (arena offset << 24) | piece count */
@@ -80,68 +79,38 @@ struct DeviceArgs {
   /* segment tables, in backtrack order */
   int *seg_start;   /* data index whose chromEnd starts the segment; -1 = first_chromStart */
   double *seg_mean; /* exp(best_log_mean) */
+  long long *prof;  /* PSD_PROFILE builds: per (problem, wave) cycle counters, else NULL */
 };
-
-struct ListStore {
-  double Lin[LDS_CAP], Log[LDS_CAP], Con[LDS_CAP], mn[LDS_CAP], mx[LDS_CAP], prv[LDS_CAP];
-  int di[LDS_CAP];
-};
-struct ScratchStore {
-  double lc[LDS_CAP], rc[LDS_CAP], mu[LDS_CAP], muc[LDS_CAP];
-  int cls[LDS_CAP];
-  int iv[2 * LDS_CAP];
-};
-struct SharedBlock {
-  ListStore up[2], down[2], m[2];
-  ScratchStore sc[2];
-  int n_up[2], n_down[2];
-  int abort_status;
-  int abort_err;
-  unsigned long long total_up;
-  int max_up;
-  int serial_up;
-};
-
-PSD_D ListView view_of(ListStore &s) {
-  ListView v;
-  v.Lin = s.Lin;
-  v.Log = s.Log;
-  v.Con = s.Con;
-  v.mn = s.mn;
-  v.mx = s.mx;
-  v.prv = s.prv;
-  v.di = s.di;
-  return v;
-}
-PSD_D WaveScratch scratch_of(ScratchStore &s) {
-  WaveScratch w;
-  w.lc = s.lc;
-  w.rc = s.rc;
-  w.mu = s.mu;
-  w.muc = s.muc;
-  w.cls = s.cls;
-  w.iv = s.iv;
-  return w;
-}
 
 /* f <- (f * cum_weight_prev + (weight, -coverage*weight, 0)) * (1/cum_weight)
  * exactly as drv:316-321 / 365-370: multiply, add, multiply, no contraction. */
-PSD_D void scale_add_wave(const ListView &f, int n, double cum_weight_prev, double add_linear,
+template <class L>
+PSD_D void scale_add_wave(const L &f, int n, double cum_weight_prev, double add_linear,
                           double add_log, double inv_cum_weight) {
   const int lane = lane_id();
   for (int base = 0; base < n; base += WAVE) {
     int i = base + lane;
     if (i < n) {
-      double li = f.Lin[i] * cum_weight_prev;
-      double lo = f.Log[i] * cum_weight_prev;
-      double co = f.Con[i] * cum_weight_prev;
+      double li = f.Lin(i) * cum_weight_prev;
+      double lo = f.Log(i) * cum_weight_prev;
+      double co = f.Con(i) * cum_weight_prev;
       li = li + add_linear;
       lo = lo + add_log;
       co = co + 0.0;
-      f.Lin[i] = li * inv_cum_weight;
-      f.Log[i] = lo * inv_cum_weight;
-      f.Con[i] = co * inv_cum_weight;
+      f.Lin(i) = li * inv_cum_weight;
+      f.Log(i) = lo * inv_cum_weight;
+      f.Con(i) = co * inv_cum_weight;
     }
+  }
+}
+
+template <class L>
+PSD_D void copy_list_wave(const L &src, int n, const L &dst) {
+  const int lane = lane_id();
+  for (int base = 0; base < n; base += WAVE) {
+    int i = base + lane;
+    if (i < n)
+      store_piece(dst, i, load_coef(src, i), src.mn(i), src.mx(i), src.di(i), src.prv(i));
   }
 }
 
@@ -151,7 +120,8 @@ struct ArenaCursor {
 };
 
 /* Append one function's backtrack record to the arena; returns false when it is full. */
-PSD_D bool arena_store_wave(const DeviceArgs &a, ArenaCursor &cur, const ListView &f, int n,
+template <class L>
+PSD_D bool arena_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &f, int n,
                             unsigned long long fn_index) {
   const int lane = lane_id();
   if (n > cur.room - cur.used) {
@@ -168,9 +138,9 @@ PSD_D bool arena_store_wave(const DeviceArgs &a, ArenaCursor &cur, const ListVie
   for (int base = 0; base < n; base += WAVE) {
     int i = base + lane;
     if (i < n) {
-      a.ar_mx[off + i] = f.mx[i];
-      a.ar_prv[off + i] = f.prv[i];
-      a.ar_di[off + i] = f.di[i];
+      a.ar_mx[off + i] = f.mx(i);
+      a.ar_prv[off + i] = f.prv(i);
+      a.ar_di[off + i] = f.di(i);
     }
   }
   if (lane == 0) a.fn_ref[fn_index] = (off << FN_COUNT_BITS) | (unsigned long long)n;
@@ -179,7 +149,8 @@ PSD_D bool arena_store_wave(const DeviceArgs &a, ArenaCursor &cur, const ListVie
 }
 
 /* Minimize (fpl:689-712): first strict minimum over pieces of the clamped optimum. */
-PSD_D void minimize_wave(const ListView &f, int n, double *best_cost, double *best_log_mean,
+template <class L>
+PSD_D void minimize_wave(const L &f, int n, double *best_cost, double *best_log_mean,
                          int *data_i, double *prev_log_mean) {
   const int lane = lane_id();
   double bc = PSD_INF, blm = 0.0, bprv = 0.0;
@@ -190,10 +161,10 @@ PSD_D void minimize_wave(const ListView &f, int n, double *best_cost, double *be
     if (i < n) {
       Coef c = load_coef(f, i);
       lm = argmin(c);
-      if (lm < f.mn[i]) {
-        lm = f.mn[i];
-      } else if (f.mx[i] < lm) {
-        lm = f.mx[i];
+      if (lm < f.mn(i)) {
+        lm = f.mn(i);
+      } else if (f.mx(i) < lm) {
+        lm = f.mx(i);
       }
       cost = get_cost(c, lm);
     }
@@ -211,8 +182,8 @@ PSD_D void minimize_wave(const ListView &f, int n, double *best_cost, double *be
       bc = mn;
       blm = shfl_d(lm, src);
       int ii = base + src;
-      bdi = f.di[ii];
-      bprv = f.prv[ii];
+      bdi = f.di(ii);
+      bprv = f.prv(ii);
     }
   }
   *best_cost = bc;
@@ -221,25 +192,29 @@ PSD_D void minimize_wave(const ListView &f, int n, double *best_cost, double *be
   *prev_log_mean = bprv;
 }
 
+/* list ids in g_sm.list[]: 2*chain + buffer for the two cost functions (chain 0 = up,
+ * 1 = down), 4 + chain for the chain's min-less / min-more temporary */
 __global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
-  __shared__ SharedBlock sm;
   const int p = (int)blockIdx.x;
-  const int wave = wave_id();
+  const int chain = wave_id();
   const int lane = lane_id();
   const int contig = a.prob_contig[p];
   const int N = a.contig_n[contig];
   const double penalty = a.prob_penalty[p];
   const int *count = a.count + a.contig_off[contig];
   const int *weight = a.weight + a.contig_off[contig];
-  const unsigned long long fn0 = (unsigned long long)a.prob_fn_off[p];
-  const WaveScratch sc = scratch_of(sm.sc[wave]);
-  const ListView mview = view_of(sm.m[wave]);
+  const unsigned long long fn0 =
+      (unsigned long long)a.prob_fn_off[p] + (chain == 1 ? (unsigned long long)N : 0ull);
+  const LdsList mlist = lds_list(4 + chain);
 
   if (threadIdx.x == 0) {
-    sm.abort_status = 0;
-    sm.abort_err = 0;
-    sm.n_up[0] = sm.n_up[1] = 0;
-    sm.n_down[0] = sm.n_down[1] = 0;
+    g_sm.abort_status[0] = g_sm.abort_status[1] = 0;
+    g_sm.abort_err[0] = g_sm.abort_err[1] = 0;
+    for (int i = 0; i < 6; i++) g_sm.n[i] = 0;
+    g_sm.serial[0] = g_sm.serial[1] = 0;
+#ifdef PSD_PROFILE
+    for (int i = 0; i < N_PROF; i++) g_sm.prof[0][i] = g_sm.prof[1][i] = 0;
+#endif
   }
   __syncthreads();
 
@@ -249,14 +224,16 @@ __global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
   cur.room = 0;
   unsigned long long total_intervals = 0;
   int max_intervals = 0;
-  int n_serial = 0;
-  int err = 0;
   int status = 0;
   double cum_weight_i = 0.0, cum_weight_prev_i = -1.0;
   int cnt_reg = 0, wt_reg = 0;
-  int b = 0; /* sm.up[b], sm.down[b] hold step t-1 */
+  int b = 0; /* buffer holding step t-1 */
   int t = 0;
+#ifdef PSD_PROFILE
+  long long t_begin = cycle_now();
+#endif
   for (; t < N; t++) {
+    PSD_PROF_T0();
     if ((t & 63) == 0) { /* coalesced read of the next 64 data points */
       int tt = t + lane;
       cnt_reg = tt < N ? count[tt] : 0;
@@ -266,117 +243,120 @@ __global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
     const double w = (double)shfl_i(wt_reg, t & 63);
     cum_weight_i += w;
     const int nb = b ^ 1;
+    const LdsList own_prev = lds_list(2 * chain + b);
+    const LdsList own_new = lds_list(2 * chain + nb);
+    const LdsList other_prev = lds_list(2 * (1 - chain) + b);
+    const int n_own = uniform_i(g_sm.n[own_prev.id]);
+    const int n_other = uniform_i(g_sm.n[other_prev.id]);
     int n_new = 0;
     if (t == 0) {
       /* C^down_1 = gamma_1 / w_1 (drv:266-270); there is no up function yet */
-      if (wave == 1) {
+      if (chain == 1) {
         if (lane == 0) {
           Coef c;
           c.Linear = 1.0;
           c.Log = (double)(-coverage);
           c.Constant = 0.0;
-          store_piece(view_of(sm.down[nb]), 0, c, a.contig_min_log_mean[contig],
+          store_piece(own_new, 0, c, a.contig_min_log_mean[contig],
                       a.contig_max_log_mean[contig], -1, -5.0);
         }
         n_new = 1;
       }
     } else {
-      const double add_linear = w;
-      const double add_log = (double)(-coverage) * w;
-      const double inv_cw = 1 / cum_weight_i;
-      if (wave == 0) { /* up_t (drv:273-321) */
-        const ListView dprev = view_of(sm.down[b]);
-        const ListView unew = view_of(sm.up[nb]);
-        const double pen_term = penalty / cum_weight_prev_i;
+      /* up_t   = min_env(min_less(down_{t-1}) + penalty/W_{t-1}, up_{t-1})   drv:273-300
+       * down_t = min_env(min_more(up_{t-1}),                    down_{t-1})  drv:324-349
+       * (t == 1: up_1 = the min-less result, down_1 = down_0) */
+      int nm = 0;
+      if (chain == 0) {
+        nm = min_less_wave(other_prev, n_other, mlist, LDS_CAP, t - 1,
+                           penalty / cum_weight_prev_i);
+      } else if (t >= 2) {
+        nm = min_more_wave(other_prev, n_other, mlist, LDS_CAP, t - 1);
+      }
+      if (nm >= 0) {
         if (t == 1) {
-          n_new = min_less_wave(dprev, sm.n_down[b], unew, LDS_CAP, sc, t - 1, pen_term, &err);
-        } else {
-          int nm = min_less_wave(dprev, sm.n_down[b], mview, LDS_CAP, sc, t - 1, pen_term, &err);
-          if (!(err & WERR_OVERFLOW))
-            n_new = min_env_wave(mview, nm, view_of(sm.up[b]), sm.n_up[b], unew, LDS_CAP, sc,
-                                 2 * LDS_CAP, &n_serial, &err);
-        }
-        wave_sync();
-        scale_add_wave(unew, n_new, cum_weight_prev_i, add_linear, add_log, inv_cw);
-      } else { /* down_t (drv:324-370) */
-        const ListView dprev = view_of(sm.down[b]);
-        const ListView dnew = view_of(sm.down[nb]);
-        if (t == 1) {
-          n_new = sm.n_down[b];
-          for (int base = 0; base < n_new; base += WAVE) {
-            int i = base + lane;
-            if (i < n_new)
-              store_piece(dnew, i, load_coef(dprev, i), dprev.mn[i], dprev.mx[i], dprev.di[i],
-                          dprev.prv[i]);
+          if (chain == 0) {
+            copy_list_wave(mlist, nm, own_new);
+            n_new = nm;
+          } else {
+            copy_list_wave(own_prev, n_own, own_new);
+            n_new = n_own;
           }
         } else {
-          int head = 0;
-          int nm = min_more_wave(view_of(sm.up[b]), sm.n_up[b], mview, LDS_CAP, sc, t - 1, &head,
-                                 &err);
-          if (!(err & WERR_OVERFLOW))
-            n_new = min_env_wave(list_offset(mview, head), nm, dprev, sm.n_down[b], dnew, LDS_CAP,
-                                 sc, 2 * LDS_CAP, &n_serial, &err);
+          const LdsList f1 = chain == 0 ? mlist : mlist.shifted(LDS_CAP - nm);
+          n_new = min_env_wave(f1, nm, own_prev, n_own, own_new, LDS_CAP);
         }
+      } else {
+        n_new = nm;
+      }
+      if (n_new >= 0) {
+        PSD_PROF_T0();
         wave_sync();
-        scale_add_wave(dnew, n_new, cum_weight_prev_i, add_linear, add_log, inv_cw);
+        /* then multiply, add the data point, multiply (drv:316-321,365-370) */
+        scale_add_wave(own_new, n_new, cum_weight_prev_i, w, (double)(-coverage) * w,
+                       1 / cum_weight_i);
+        wave_sync();
+        PSD_PROF_ADD(PROF_SCALE);
       }
     }
-    wave_sync();
     /* ---- end of step: publish sizes, commit the backtrack record ---- */
-    unsigned long long any_err = ballot(err != 0);
-    if (any_err) {
-      int e = 0;
-      for (int l = 0; l < WAVE; l++) e |= shfl_i(err, l);
-      if (lane == 0) {
-        sm.abort_err = e; /* both waves may write: either value is a valid report */
-        sm.abort_status = (e & WERR_OVERFLOW) ? PST_LDS_OVERFLOW : PST_REF_THROW;
-      }
-    } else if (wave == 0) {
-      if (t > 0) {
-        if (!arena_store_wave(a, cur, view_of(sm.up[nb]), n_new, fn0 + (unsigned long long)t)) {
-          if (lane == 0) sm.abort_status = PST_ARENA_FULL;
+    {
+      PSD_PROF_T0();
+      if (n_new < 0) {
+        if (lane == 0) {
+          g_sm.abort_err[t & 1] = -n_new;
+          g_sm.abort_status[t & 1] = ((-n_new) & WERR_OVERFLOW) ? PST_LDS_OVERFLOW : PST_REF_THROW;
+        }
+        n_new = 0;
+      } else if (chain == 1 || t > 0) {
+        if (!arena_store_wave(a, cur, own_new, n_new, fn0 + (unsigned long long)t)) {
+          if (lane == 0) g_sm.abort_status[t & 1] = PST_ARENA_FULL;
         }
       }
-      if (lane == 0) sm.n_up[nb] = n_new;
-    } else {
-      if (!arena_store_wave(a, cur, view_of(sm.down[nb]), n_new,
-                            fn0 + (unsigned long long)N + (unsigned long long)t)) {
-        if (lane == 0) sm.abort_status = PST_ARENA_FULL;
-      }
-      if (lane == 0) sm.n_down[nb] = n_new;
+      if (lane == 0) g_sm.n[own_new.id] = n_new;
+      PSD_PROF_ADD(PROF_ARENA);
+      total_intervals += (unsigned long long)n_new;
+      if (max_intervals < n_new) max_intervals = n_new;
+      cum_weight_prev_i = cum_weight_i;
+      __syncthreads();
+      PSD_PROF_ADD(PROF_BARRIER);
     }
-    total_intervals += (unsigned long long)n_new;
-    if (max_intervals < n_new) max_intervals = n_new;
-    cum_weight_prev_i = cum_weight_i;
-    __syncthreads();
-    status = sm.abort_status;
+    status = uniform_i(g_sm.abort_status[t & 1]);
     if (status != 0) break;
+    if (lane == 0) g_sm.abort_status[(t + 1) & 1] = 0;
     b = nb;
   }
   /* ---- after the last data point: Minimize the final down function (drv:404-406) ---- */
-  if (wave == 0 && lane == 0) {
-    sm.total_up = total_intervals;
-    sm.max_up = max_intervals;
-    sm.serial_up = n_serial;
+  if (chain == 0 && lane == 0) {
+    g_sm.total_up = total_intervals;
+    g_sm.max_up = max_intervals;
   }
   __syncthreads();
-  if (wave == 1) {
+#ifdef PSD_PROFILE
+  if (lane == 0 && a.prof) {
+    long long *dst = a.prof + ((long long)p * 2 + chain) * N_PROF;
+    for (int i = 0; i < N_PROF; i++) dst[i] = g_sm.prof[chain][i];
+    dst[PROF_TOTAL] = cycle_now() - t_begin;
+  }
+#endif
+  if (chain == 1) {
     ProbResult r;
     r.best_cost = 0.0;
     r.best_log_mean = 0.0;
     r.prev_log_mean = 0.0;
     r.prev_seg_end = -1;
     r.status = status;
-    r.wave_err = sm.abort_err;
-    r.max_intervals = max_intervals > sm.max_up ? max_intervals : sm.max_up;
-    r.total_intervals = total_intervals + sm.total_up;
+    r.wave_err = g_sm.abort_err[0] | g_sm.abort_err[1];
+    r.max_intervals = max_intervals > g_sm.max_up ? max_intervals : g_sm.max_up;
+    r.total_intervals = total_intervals + g_sm.total_up;
     r.n_segments = 0;
     r.n_equality = 0;
-    r.n_serial_env = n_serial + sm.serial_up;
+    r.n_serial_env = g_sm.serial[0] + g_sm.serial[1];
     r.step_reached = t;
     if (status == 0) {
-      minimize_wave(view_of(sm.down[b]), sm.n_down[b], &r.best_cost, &r.best_log_mean,
-                    &r.prev_seg_end, &r.prev_log_mean);
+      const int id = 2 + b;
+      minimize_wave(lds_list(id), g_sm.n[id], &r.best_cost, &r.best_log_mean, &r.prev_seg_end,
+                    &r.prev_log_mean);
     }
     if (lane == 0) a.result[p] = r;
   }
@@ -407,7 +387,7 @@ __global__ __launch_bounds__(64) void fpop_backtrack_kernel(DeviceArgs a) {
     int n = (int)(ref & ((1ull << FN_COUNT_BITS) - 1));
     if (lane == 0) {
       seg_start[n_seg] = prev_seg_end;
-      seg_mean[n_seg] = psd_exp(best_log_mean);
+      seg_mean[n_seg] = d_exp(best_log_mean);
     }
     n_seg++;
     prev_seg_offset = prev_seg_offset == 0 ? N : 0;
@@ -448,7 +428,7 @@ __global__ __launch_bounds__(64) void fpop_backtrack_kernel(DeviceArgs a) {
   if (lane == 0) {
     if (status == 0) {
       seg_start[n_seg] = -1;
-      seg_mean[n_seg] = psd_exp(best_log_mean);
+      seg_mean[n_seg] = d_exp(best_log_mean);
       n_seg++;
     }
     a.result[p].n_segments = n_seg;
@@ -459,7 +439,7 @@ __global__ __launch_bounds__(64) void fpop_backtrack_kernel(DeviceArgs a) {
 
 __global__ void math_probe_kernel(int op, int n, const double *x, double *y) {
   int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (i < n) y[i] = op == 0 ? psd_exp(x[i]) : psd_log(x[i]);
+  if (i < n) y[i] = op == 0 ? d_exp(x[i]) : d_log(x[i]);
 }
 
 }  // namespace psd

@@ -29,11 +29,17 @@ struct Coef {
 
 PSD_D double absd(double x) { return x < 0 ? -x : x; } /* fpl:13 ABS */
 
+/* Leaf math stays inline: an out-of-line exp/log/root makes every caller spill its live
+ * doubles to scratch around the call.  Code size is controlled one level up instead (the
+ * wave operations of fpop_wave.h are the out-of-line units). */
+PSD_D double d_exp(double x) { return psd_exp(x); }
+PSD_D double d_log(double x) { return psd_log(x); }
+
 /* fpl:192-197 */
 PSD_D double argmin_mean(const Coef &c) { return -c.Log / c.Linear; }
 
 /* fpl:199-204 */
-PSD_D double argmin(const Coef &c) { return psd_log(argmin_mean(c)); }
+PSD_D double argmin(const Coef &c) { return d_log(argmin_mean(c)); }
 
 /* fpl:206-222 */
 PSD_D double get_cost(const Coef &c, double log_mean) {
@@ -41,7 +47,7 @@ PSD_D double get_cost(const Coef &c, double log_mean) {
   if (log_mean == -PSD_INF) {
     linear_term = 0.0;
   } else {
-    linear_term = c.Linear * psd_exp(log_mean);
+    linear_term = c.Linear * d_exp(log_mean);
   }
   if (c.Log == 0) {
     log_term = 0.0;
@@ -57,14 +63,14 @@ PSD_D double poisson_loss(const Coef &c, double mean) {
   if (c.Log == 0) {
     return loss_without_log_term;
   }
-  double product = psd_log(mean) * c.Log;
+  double product = d_log(mean) * c.Log;
   return loss_without_log_term + product;
 }
 
 /* fpl:29-50; caller guarantees c.Log != 0 (the reference throws otherwise) */
 PSD_D bool has_two_roots(const Coef &c, double equals) {
   double optimal_mean = argmin_mean(c);
-  double optimal_log_mean = psd_log(optimal_mean);
+  double optimal_log_mean = d_log(optimal_mean);
   double optimal_cost = get_cost(c, optimal_log_mean);
   double optimal_cost2 = poisson_loss(c, optimal_mean);
   if (0 < c.Linear) {
@@ -108,15 +114,15 @@ PSD_D double get_larger_root(const Coef &c, double max_log_mean, double equals) 
       double between_closest = (closest_positive_mean + closest_negative_mean) / 2;
       double between_cost = poisson_loss(c, between_closest) - equals;
       if (absd(between_cost) < absd(candidate_cost)) {
-        return psd_log(between_closest);
+        return d_log(between_closest);
       } else {
-        return psd_log(candidate_root);
+        return d_log(candidate_root);
       }
     }
     deriv = c.Linear + c.Log / candidate_root; /* PoissonDeriv fpl:63-65 */
     candidate_root = candidate_root - candidate_cost / deriv;
   } while (NEWTON_EPSILON < absd(candidate_cost));
-  return psd_log(candidate_root);
+  return d_log(candidate_root);
 }
 
 /* fpl:129-190: Newton in log-mean space from argmin-1. */
@@ -146,7 +152,7 @@ PSD_D double get_smaller_root(const Coef &c, double min_log_mean, double equals)
     if (candidate_root == -PSD_INF) {
       linear_term = 0.0;
     } else {
-      linear_term = c.Linear * psd_exp(candidate_root);
+      linear_term = c.Linear * d_exp(candidate_root);
     }
     double log_term = (c.Log == 0) ? 0.0 : c.Log * candidate_root;
     candidate_cost = (linear_term + log_term + c.Constant) - equals;

@@ -1,8 +1,8 @@
 /* fpop_wave.h -- wavefront-level operations on piecewise Poisson-loss functions.
  *
  * One gfx950 wavefront (64 lanes) owns one cost function.  A function is a list of pieces
- * in struct-of-arrays form (LDS when it fits, an HBM scratch area otherwise); lane i works
- * on piece / merged interval i (in chunks of 64 for longer lists).
+ * in struct-of-arrays form in LDS (an HBM scratch accessor can be plugged into the same
+ * templates); lane i works on piece / merged interval i (chunks of 64 for longer lists).
  *
  * These are re-designs, not translations, of the reference's sequential std::list walks
  * (/root/reference/src/funPieceListLog.cpp, "fpl"):
@@ -23,6 +23,9 @@
  *     used when every "same function" decision is also a bitwise equality (then comparing
  *     with the predecessor is equivalent); otherwise lane 0 replays the interval list
  *     sequentially (rare; counted in the stats).
+ *
+ * The three operations are out-of-line functions returning the piece count (>= 0) or
+ * -(WERR_* bits): the fully inlined kernel was ~200 KB of code against a 64 KB I-cache.
  */
 #ifndef PSD_FPOP_WAVE_H
 #define PSD_FPOP_WAVE_H
@@ -35,74 +38,125 @@
 
 namespace psd {
 
-/* struct-of-arrays view of one piece list (funPieceListLog.h:11-34 fields) */
-struct ListView {
-  double *Lin, *Log, *Con, *mn, *mx, *prv;
-  int *di;
+constexpr int LDS_CAP = 128; /* pieces per LDS-resident list */
+
+/* one piece list, struct-of-arrays (fields of funPieceListLog.h:11-34) */
+struct ListStore {
+  double Lin[LDS_CAP], Log[LDS_CAP], Con[LDS_CAP], mn[LDS_CAP], mx[LDS_CAP], prv[LDS_CAP];
+  int di[LDS_CAP];
+};
+/* per-wave temporaries, one slot per input piece / merged interval */
+struct ScratchStore {
+  double lc[LDS_CAP], rc[LDS_CAP], mu[LDS_CAP], muc[LDS_CAP];
+  int cls[LDS_CAP];
+  int iv[2 * LDS_CAP];
+};
+constexpr int N_PROF = 12;
+/* the workgroup's LDS: lists 0,1 = up (double-buffered), 2,3 = down, 4,5 = per-wave
+ * min-less / min-more result */
+struct SharedBlock {
+  ListStore list[6];
+  ScratchStore sc[2];
+  int n[6];
+  int abort_status[2];
+  int abort_err[2];
+  unsigned long long total_up;
+  int max_up;
+  int serial[2];
+#ifdef PSD_PROFILE
+  long long prof[2][N_PROF];
+#endif
 };
 
-PSD_D ListView list_offset(const ListView &L, int off) {
-  ListView r;
-  r.Lin = L.Lin + off;
-  r.Log = L.Log + off;
-  r.Con = L.Con + off;
-  r.mn = L.mn + off;
-  r.mx = L.mx + off;
-  r.prv = L.prv + off;
-  r.di = L.di + off;
+PSD_LDS SharedBlock g_sm;
+
+#ifdef PSD_PROFILE
+#define PSD_PROF_T0() long long prof_t0_ = cycle_now()
+#define PSD_PROF_ADD(slot)                                             \
+  do {                                                                 \
+    long long now_ = cycle_now();                                      \
+    if (lane_id() == 0) g_sm.prof[wave_id()][slot] += now_ - prof_t0_; \
+    prof_t0_ = now_;                                                   \
+  } while (0)
+#else
+#define PSD_PROF_T0() \
+  do {                \
+  } while (0)
+#define PSD_PROF_ADD(slot) \
+  do {                     \
+  } while (0)
+#endif
+enum {
+  PROF_PRE = 0, PROF_WALK = 1, PROF_TABLE = 2, PROF_CLASSIFY = 3, PROF_COMPACT = 4,
+  PROF_SCALE = 5, PROF_ARENA = 6, PROF_BARRIER = 7, PROF_SERIAL = 8, PROF_TOTAL = 9
+};
+
+/* accessor of an LDS-resident list: g_sm.list[id], elements off.. */
+struct LdsList {
+  int id, off;
+  PSD_M double &Lin(int i) const { return g_sm.list[id].Lin[off + i]; }
+  PSD_M double &Log(int i) const { return g_sm.list[id].Log[off + i]; }
+  PSD_M double &Con(int i) const { return g_sm.list[id].Con[off + i]; }
+  PSD_M double &mn(int i) const { return g_sm.list[id].mn[off + i]; }
+  PSD_M double &mx(int i) const { return g_sm.list[id].mx[off + i]; }
+  PSD_M double &prv(int i) const { return g_sm.list[id].prv[off + i]; }
+  PSD_M int &di(int i) const { return g_sm.list[id].di[off + i]; }
+  PSD_M LdsList shifted(int d) const {
+    LdsList r;
+    r.id = id;
+    r.off = off + d;
+    return r;
+  }
+};
+PSD_D LdsList lds_list(int id) {
+  LdsList r;
+  r.id = id;
+  r.off = 0;
   return r;
 }
 
-PSD_D Coef load_coef(const ListView &L, int i) {
+template <class L>
+PSD_D Coef load_coef(const L &f, int i) {
   Coef c;
-  c.Linear = L.Lin[i];
-  c.Log = L.Log[i];
-  c.Constant = L.Con[i];
+  c.Linear = f.Lin(i);
+  c.Log = f.Log(i);
+  c.Constant = f.Con(i);
   return c;
 }
 
-PSD_D void store_piece(const ListView &L, int i, const Coef &c, double mn, double mx, int di,
+template <class L>
+PSD_D void store_piece(const L &f, int i, const Coef &c, double mn, double mx, int di,
                        double prv) {
-  L.Lin[i] = c.Linear;
-  L.Log[i] = c.Log;
-  L.Con[i] = c.Constant;
-  L.mn[i] = mn;
-  L.mx[i] = mx;
-  L.di[i] = di;
-  L.prv[i] = prv;
+  f.Lin(i) = c.Linear;
+  f.Log(i) = c.Log;
+  f.Con(i) = c.Constant;
+  f.mn(i) = mn;
+  f.mx(i) = mx;
+  f.di(i) = di;
+  f.prv(i) = prv;
 }
-
-/* per-wave temporaries, one slot per input piece / merged interval */
-struct WaveScratch {
-  double *lc, *rc, *mu, *muc; /* cost at left end, right end, argmin, cost at argmin */
-  int *cls;                   /* search-mode decision */
-  int *iv;                    /* merged interval k -> (i1 << 16) | i2 */
-};
 
 enum { CLS_STORE = 0, CLS_CONST_EDGE = 1, CLS_CONST_MU = 2 };
 
-/* error bits reported by the wave ops (the reference would throw / loop / read a sentinel) */
+/* error bits (the reference would throw / loop / read a sentinel) */
 enum {
-  WERR_OVERFLOW = 1,      /* output does not fit `cap`: caller retries in spill mode */
+  WERR_OVERFLOW = 1,      /* output does not fit `cap` */
   WERR_REF_THROW = 2,     /* fpl:380 decreasing degenerate linear piece */
   WERR_SENTINEL = 4,      /* push_min_pieces neighbour outside the list */
   WERR_ZERO_INTERVAL = 8, /* fpl:933 zero-size merged interval */
 };
 
-/* ------------------------------------------------------------------------------------- */
-/* min-less: out(x) = min_{y<=x} in(y).  Returns the number of output pieces (all with
- * data_i = data_i_out, as the driver's set_prev_seg_end() does next, and Constant shifted
- * by `add_const`, as its add(0,0,penalty/cum_weight_prev) does: PeakSegFPOPLog.cpp:290-296). */
-PSD_D int min_less_wave(const ListView &in, int n, const ListView &out, int cap,
-                        const WaveScratch &s, int data_i_out, double add_const, int *err) {
+/* Shared first half of min-less / min-more: per piece, the costs at both ends, the argmin
+ * and its cost (fpl:245-246,310-311 / 469-470,483-485). */
+template <class L>
+PSD_D void piece_costs_wave(const L &in, int n, ScratchStore &s) {
   const int lane = lane_id();
-  /* pass 1: state-independent quantities of every piece (fpl:245-246,310-311) */
   for (int base = 0; base < n; base += WAVE) {
     int i = base + lane;
     if (i < n) {
       Coef c = load_coef(in, i);
-      double lc = get_cost(c, in.mn[i]);
-      double rc = get_cost(c, in.mx[i]);
+      double lc = get_cost(c, in.mn(i));
+      double rc = get_cost(c, in.mx(i));
       double mu = 0.0, muc = 0.0;
       if (c.Log != 0) {
         mu = argmin(c);
@@ -115,11 +169,23 @@ PSD_D int min_less_wave(const ListView &in, int n, const ListView &out, int cap,
     }
   }
   wave_sync();
-  /* pass 2: what the walk does with piece i when it reaches it in search mode */
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* min-less: out(x) = min_{y<=x} in(y).  All output pieces get data_i = data_i_out (the
+ * driver's set_prev_seg_end) and Constant += add_const (its add(0,0,penalty/cum_weight_prev),
+ * PeakSegFPOPLog.cpp:290-296). */
+template <class L>
+PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, int data_i_out, double add_const) {
+  const int lane = lane_id();
+  ScratchStore &s = g_sm.sc[wave_id()];
+  PSD_PROF_T0();
+  piece_costs_wave(in, n, s);
+  /* what the walk does with piece i when it reaches it in search mode */
   for (int base = 0; base < n; base += WAVE) {
     int i = base + lane;
     if (i < n) {
-      double Log_i = in.Log[i];
+      double Log_i = in.Log(i);
       double lc = s.lc[i], rc = s.rc[i];
       bool has_next = i + 1 < n;
       double next_left_cost = has_next ? s.lc[i + 1] : PSD_INF;
@@ -138,9 +204,9 @@ PSD_D int min_less_wave(const ListView &in, int n, const ListView &out, int cap,
         bool next_ok = true;
         if (has_next) next_ok = NEWTON_EPSILON < next_left_cost - mu_cost;
         bool cost_ok = NEWTON_EPSILON < rc - mu_cost && next_ok;
-        if (mu <= in.mn[i] && cost_ok) {
+        if (mu <= in.mn(i) && cost_ok) {
           cls = CLS_CONST_EDGE;
-        } else if (mu < in.mx[i] && cost_ok) {
+        } else if (mu < in.mx(i) && cost_ok) {
           cls = CLS_CONST_MU;
         } else {
           cls = CLS_STORE;
@@ -150,10 +216,12 @@ PSD_D int min_less_wave(const ListView &in, int n, const ListView &out, int cap,
     }
   }
   wave_sync();
+  PSD_PROF_ADD(PROF_PRE);
 
+  int err = 0;
   int n_out = 0;
   int i0 = 0;
-  double prev_min_log_mean = in.mn[0];
+  double prev_min_log_mean = in.mn(0);
   for (;;) {
     /* ---- search mode: first piece j >= i0 that starts a constant ---- */
     int j = n;
@@ -168,10 +236,7 @@ PSD_D int min_less_wave(const ListView &in, int n, const ListView &out, int cap,
     }
     /* pieces i0..j-1 are kept as they are (fpl:303-307,361-364) */
     int cnt = j - i0;
-    if (n_out + cnt + 2 > cap) {
-      *err |= WERR_OVERFLOW;
-      return 0;
-    }
+    if (n_out + cnt + 2 > cap) return -WERR_OVERFLOW;
     for (int base = i0; base < j; base += WAVE) {
       int i = base + lane;
       if (i < j) {
@@ -179,12 +244,12 @@ PSD_D int min_less_wave(const ListView &in, int n, const ListView &out, int cap,
         c.Constant = c.Constant + add_const;
         c.Linear = c.Linear + 0.0;
         c.Log = c.Log + 0.0;
-        double lo = (i == i0) ? prev_min_log_mean : in.mn[i];
-        store_piece(out, n_out + (i - i0), c, lo, in.mx[i], data_i_out, PSD_INF);
+        double lo = (i == i0) ? prev_min_log_mean : in.mn(i);
+        store_piece(out, n_out + (i - i0), c, lo, in.mx(i), data_i_out, PSD_INF);
       }
     }
     n_out += cnt;
-    if (cnt > 0) prev_min_log_mean = in.mx[j - 1];
+    if (cnt > 0) prev_min_log_mean = in.mx(j - 1);
     if (j == n) break;
     /* ---- piece j starts a constant piece ---- */
     double prev_min_cost, prev_best_log_mean;
@@ -205,7 +270,7 @@ PSD_D int min_less_wave(const ListView &in, int n, const ListView &out, int cap,
       prev_min_cost = s.muc[j];
     } else { /* fpl:288-292,328-336 */
       prev_min_cost = s.lc[j];
-      prev_best_log_mean = in.mn[j];
+      prev_best_log_mean = in.mn(j);
     }
     /* ---- constant mode: first piece k > j where the constant ends (fpl:367-422) ---- */
     int k_ev = -1;
@@ -221,8 +286,8 @@ PSD_D int min_less_wave(const ListView &in, int n, const ListView &out, int cap,
           if (c.Linear < 0) bad = true; /* fpl:378-380 */
         } else {
           if (has_two_roots(c, prev_min_cost)) {
-            mu = get_smaller_root(c, in.mn[k], prev_min_cost);
-            inside = in.mn[k] < mu && mu < in.mx[k];
+            mu = get_smaller_root(c, in.mn(k), prev_min_cost);
+            inside = in.mn(k) < mu && mu < in.mx(k);
           }
           if (!inside) at_right = s.rc[k] <= prev_min_cost + NEWTON_EPSILON;
         }
@@ -230,7 +295,7 @@ PSD_D int min_less_wave(const ListView &in, int n, const ListView &out, int cap,
       unsigned long long m_ev = ballot(inside || at_right);
       unsigned long long m_bad = ballot(bad);
       unsigned long long visited = m_ev ? lanes_below(ctz64(m_ev)) : ~0ull;
-      if (m_bad & visited) *err |= WERR_REF_THROW;
+      if (m_bad & visited) err |= WERR_REF_THROW;
       if (m_ev) {
         int src = ctz64(m_ev);
         k_ev = base + src;
@@ -245,7 +310,7 @@ PSD_D int min_less_wave(const ListView &in, int n, const ListView &out, int cap,
     cc.Constant = prev_min_cost + add_const;
     if (k_ev < 0) { /* constant runs to the end (fpl:429-436) */
       if (lane == 0)
-        store_piece(out, n_out, cc, prev_min_log_mean, in.mx[n - 1], data_i_out,
+        store_piece(out, n_out, cc, prev_min_log_mean, in.mx(n - 1), data_i_out,
                     prev_best_log_mean);
       n_out++;
       break;
@@ -257,7 +322,7 @@ PSD_D int min_less_wave(const ListView &in, int n, const ListView &out, int cap,
       prev_min_log_mean = ev_mu;
       i0 = k_ev;
     } else { /* constant ends on the right end of piece k (fpl:410-420) */
-      double mxk = in.mx[k_ev];
+      double mxk = in.mx(k_ev);
       if (lane == 0)
         store_piece(out, n_out, cc, prev_min_log_mean, mxk, data_i_out, prev_best_log_mean);
       n_out++;
@@ -267,39 +332,24 @@ PSD_D int min_less_wave(const ListView &in, int n, const ListView &out, int cap,
     }
   }
   wave_sync();
-  return n_out;
+  PSD_PROF_ADD(PROF_WALK);
+  return err ? -err : n_out;
 }
 
 /* ------------------------------------------------------------------------------------- */
 /* min-more: out(x) = min_{y>=x} in(y).  The reference builds the list with emplace_front;
- * here pieces are written downwards from out[cap-1], and the result is out[head..cap). The
- * return value is the piece count; *head_out = cap - count.  data_i as for min_less. */
-PSD_D int min_more_wave(const ListView &in, int n, const ListView &out, int cap,
-                        const WaveScratch &s, int data_i_out, int *head_out, int *err) {
+ * here pieces are written downwards from out[cap-1]: the result is out[cap-n .. cap). */
+template <class L>
+PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, int data_i_out) {
   const int lane = lane_id();
-  for (int base = 0; base < n; base += WAVE) {
-    int i = base + lane;
-    if (i < n) {
-      Coef c = load_coef(in, i);
-      double lc = get_cost(c, in.mn[i]);
-      double rc = get_cost(c, in.mx[i]);
-      double mu = 0.0, muc = 0.0;
-      if (c.Log != 0) {
-        mu = argmin(c);
-        muc = get_cost(c, mu);
-      }
-      s.lc[i] = lc;
-      s.rc[i] = rc;
-      s.mu[i] = mu;
-      s.muc[i] = muc;
-    }
-  }
-  wave_sync();
+  ScratchStore &s = g_sm.sc[wave_id()];
+  PSD_PROF_T0();
+  piece_costs_wave(in, n, s);
   for (int base = 0; base < n; base += WAVE) {
     int i = base + lane;
     if (i < n) {
       int cls;
-      if (in.Log[i] == 0) { /* fpl:458-467 */
+      if (in.Log(i) == 0) { /* fpl:458-467 */
         cls = CLS_STORE;
       } else { /* fpl:468-548 */
         double mu = s.mu[i], mu_cost = s.muc[i];
@@ -309,10 +359,10 @@ PSD_D int min_more_wave(const ListView &in, int n, const ListView &out, int cap,
           prev_ok = NEWTON_EPSILON < prev_cost_right - mu_cost;
         }
         double this_cost_left = s.lc[i];
-        if (in.mx[i] <= mu) {
+        if (in.mx(i) <= mu) {
           double this_cost_diff = this_cost_left - s.rc[i];
           cls = (NEWTON_EPSILON < this_cost_diff) ? CLS_CONST_EDGE : CLS_STORE;
-        } else if (in.mn[i] < mu && NEWTON_EPSILON < this_cost_left - mu_cost && prev_ok) {
+        } else if (in.mn(i) < mu && NEWTON_EPSILON < this_cost_left - mu_cost && prev_ok) {
           cls = CLS_CONST_MU;
         } else {
           cls = CLS_STORE;
@@ -322,11 +372,11 @@ PSD_D int min_more_wave(const ListView &in, int n, const ListView &out, int cap,
     }
   }
   wave_sync();
+  PSD_PROF_ADD(PROF_PRE);
 
   int n_out = 0; /* pieces written so far; piece p lives at out[cap-1-p] */
   int i0 = n - 1;
-  double prev_max_log_mean = in.mx[n - 1];
-  const Coef czero = {0.0, 0.0, 0.0};
+  double prev_max_log_mean = in.mx(n - 1);
   for (;;) {
     /* ---- search mode, walking down from i0: first piece j <= i0 starting a constant ---- */
     int j = -1;
@@ -340,20 +390,17 @@ PSD_D int min_more_wave(const ListView &in, int n, const ListView &out, int cap,
       }
     }
     int cnt = i0 - j;
-    if (n_out + cnt + 2 > cap) {
-      *err |= WERR_OVERFLOW;
-      return 0;
-    }
+    if (n_out + cnt + 2 > cap) return -WERR_OVERFLOW;
     for (int base = i0; base > j; base -= WAVE) {
       int i = base - lane;
       if (i > j) {
         Coef c = load_coef(in, i);
-        double hi = (i == i0) ? prev_max_log_mean : in.mx[i];
-        store_piece(out, cap - 1 - (n_out + (i0 - i)), c, in.mn[i], hi, data_i_out, PSD_INF);
+        double hi = (i == i0) ? prev_max_log_mean : in.mx(i);
+        store_piece(out, cap - 1 - (n_out + (i0 - i)), c, in.mn(i), hi, data_i_out, PSD_INF);
       }
     }
     n_out += cnt;
-    if (cnt > 0) prev_max_log_mean = in.mn[j + 1];
+    if (cnt > 0) prev_max_log_mean = in.mn(j + 1);
     if (j < 0) break;
     double prev_min_cost, prev_best_log_mean;
     if (s.cls[j] == CLS_CONST_MU) { /* fpl:524-537 */
@@ -369,7 +416,7 @@ PSD_D int min_more_wave(const ListView &in, int n, const ListView &out, int cap,
       prev_min_cost = s.muc[j];
     } else { /* fpl:500-510 */
       prev_min_cost = s.rc[j];
-      prev_best_log_mean = in.mx[j];
+      prev_best_log_mean = in.mx(j);
     }
     /* ---- constant mode: highest piece k < j where the constant ends (fpl:549-602) ---- */
     int k_ev = -1;
@@ -382,13 +429,13 @@ PSD_D int min_more_wave(const ListView &in, int n, const ListView &out, int cap,
       if (k >= 0) {
         Coef c = load_coef(in, k);
         if (c.Log == 0) {
-          mu = psd_log((prev_min_cost - c.Constant) / c.Linear); /* fpl:563 */
+          mu = d_log((prev_min_cost - c.Constant) / c.Linear); /* fpl:563 */
         } else {
           if (has_two_roots(c, prev_min_cost)) {
-            mu = get_larger_root(c, in.mx[k], prev_min_cost);
+            mu = get_larger_root(c, in.mx(k), prev_min_cost);
           }
         }
-        inside = in.mn[k] < mu && mu < in.mx[k];
+        inside = in.mn(k) < mu && mu < in.mx(k);
         if (!inside) at_left = s.lc[k] <= prev_min_cost + NEWTON_EPSILON;
       }
       unsigned long long m_ev = ballot(inside || at_left);
@@ -400,11 +447,13 @@ PSD_D int min_more_wave(const ListView &in, int n, const ListView &out, int cap,
         break;
       }
     }
-    Coef cc = czero;
+    Coef cc;
+    cc.Linear = 0.0;
+    cc.Log = 0.0;
     cc.Constant = prev_min_cost;
     if (k_ev < 0) { /* constant runs to the start (fpl:608-615) */
       if (lane == 0)
-        store_piece(out, cap - 1 - n_out, cc, in.mn[0], prev_max_log_mean, data_i_out,
+        store_piece(out, cap - 1 - n_out, cc, in.mn(0), prev_max_log_mean, data_i_out,
                     prev_best_log_mean);
       n_out++;
       break;
@@ -417,7 +466,7 @@ PSD_D int min_more_wave(const ListView &in, int n, const ListView &out, int cap,
       prev_max_log_mean = ev_mu;
       i0 = k_ev;
     } else { /* fpl:591-601 */
-      double mnk = in.mn[k_ev];
+      double mnk = in.mn(k_ev);
       if (lane == 0)
         store_piece(out, cap - 1 - n_out, cc, mnk, prev_max_log_mean, data_i_out,
                     prev_best_log_mean);
@@ -428,7 +477,7 @@ PSD_D int min_more_wave(const ListView &in, int n, const ListView &out, int cap,
     }
   }
   wave_sync();
-  *head_out = cap - n_out;
+  PSD_PROF_ADD(PROF_WALK);
   return n_out;
 }
 
@@ -459,13 +508,10 @@ PSD_D void cand_push(Cands &c, int src, double lo, double hi) {
   c.n++;
 }
 
-/* push_min_pieces (fpl:870-1259) for one merged interval [last_min, first_max] of
- * it1 = c1, it2 = c2, given the two neighbour-equality flags. */
-PSD_D void env_interval(const Coef &c1, const Coef &c2, double last_min_log_mean,
-                        double first_max_log_mean, bool same_at_left, bool same_at_right,
-                        Cands &out) {
-  out.n = 0;
-  const double a = last_min_log_mean, b = first_max_log_mean;
+/* push_min_pieces (fpl:870-1259) for one merged interval [a, b] =
+ * [last_min_log_mean, first_max_log_mean] of it1 = c1, it2 = c2. */
+PSD_D void env_interval(const Coef &c1, const Coef &c2, double a, double b, bool same_at_left,
+                        bool same_at_right, Cands &out) {
   if (same_funs(c1, c2)) { /* fpl:945-951 */
     cand_push(out, 0, a, b);
     return;
@@ -474,8 +520,8 @@ PSD_D void env_interval(const Coef &c1, const Coef &c2, double last_min_log_mean
   d.Linear = c1.Linear - c2.Linear;
   d.Log = c1.Log - c2.Log;
   d.Constant = c1.Constant - c2.Constant;
-  double mid_mean = (psd_exp(b) + psd_exp(a)) / 2; /* fpl:960 */
-  double cost_diff_mid = get_cost(d, psd_log(mid_mean));
+  double mid_mean = (d_exp(b) + d_exp(a)) / 2; /* fpl:960 */
+  double cost_diff_mid = get_cost(d, d_log(mid_mean));
   if (same_at_left && same_at_right) { /* fpl:963-971 */
     cand_push(out, cost_diff_mid < 0 ? 0 : 1, a, b);
     return;
@@ -489,7 +535,7 @@ PSD_D void env_interval(const Coef &c1, const Coef &c2, double last_min_log_mean
       cand_push(out, d.Linear < 0 ? 0 : 1, a, b);
       return;
     }
-    double x = psd_log(-d.Constant / d.Linear);
+    double x = d_log(-d.Constant / d.Linear);
     if (a < x && x < b) {
       int first = (0 < d.Linear) ? 0 : 1;
       cand_push(out, first, a, x);
@@ -547,7 +593,7 @@ PSD_D void env_interval(const Coef &c1, const Coef &c2, double last_min_log_mean
   if (two_roots) {
     bool larger_inside = a < larger_log_mean && larger_log_mean < b;
     bool smaller_inside =
-        a < smaller_log_mean && 0 < psd_exp(smaller_log_mean) && smaller_log_mean < b;
+        a < smaller_log_mean && 0 < d_exp(smaller_log_mean) && smaller_log_mean < b;
     if (larger_inside) {
       if (smaller_inside && smaller_log_mean < larger_log_mean) {
         first_log_mean = smaller_log_mean;
@@ -564,8 +610,8 @@ PSD_D void env_interval(const Coef &c1, const Coef &c2, double last_min_log_mean
   if (second_log_mean != PSD_INF) {
     bool it1_larger_before;
     if (second_log_mean - first_log_mean < first_log_mean - a) {
-      double before_mean = (psd_exp(a) + psd_exp(first_log_mean)) / 2;
-      double cost_diff_before = get_cost(d, psd_log(before_mean));
+      double before_mean = (d_exp(a) + d_exp(first_log_mean)) / 2;
+      double cost_diff_before = get_cost(d, d_log(before_mean));
       it1_larger_before = cost_diff_before < 0;
     } else {
       double log_mean_between = (first_log_mean + second_log_mean) / 2;
@@ -577,8 +623,8 @@ PSD_D void env_interval(const Coef &c1, const Coef &c2, double last_min_log_mean
     cand_push(out, 1 - first, first_log_mean, second_log_mean);
     cand_push(out, first, second_log_mean, b);
   } else if (first_log_mean != PSD_INF) {
-    double before_mean = (psd_exp(a) + psd_exp(first_log_mean)) / 2;
-    double cost_diff_before = get_cost(d, psd_log(before_mean));
+    double before_mean = (d_exp(a) + d_exp(first_log_mean)) / 2;
+    double cost_diff_before = get_cost(d, d_log(before_mean));
     double after_mean = (b + first_log_mean) / 2; /* a log-mean, fpl:1216 */
     double cost_diff_after = get_cost(d, after_mean);
     if (cost_diff_before < 0) {
@@ -607,12 +653,18 @@ PSD_D void env_interval(const Coef &c1, const Coef &c2, double last_min_log_mean
   }
 }
 
-/* number of pieces with max_log_mean < x in a list sorted by max_log_mean */
-PSD_D int lower_bound_mx(const double *mx, int n, double x) {
+/* number of pieces of f (sorted by max_log_mean) with max_log_mean < x */
+template <class L>
+PSD_D int rank_mx(const L &f, int n, double x) {
+  if (n <= 32) { /* independent broadcast reads beat a dependent binary search */
+    int r = 0;
+    for (int j = 0; j < n; j++) r += f.mx(j) < x ? 1 : 0;
+    return r;
+  }
   int lo = 0, hi = n;
   while (lo < hi) {
     int mid = (lo + hi) >> 1;
-    if (mx[mid] < x) {
+    if (f.mx(mid) < x) {
       lo = mid + 1;
     } else {
       hi = mid;
@@ -623,11 +675,12 @@ PSD_D int lower_bound_mx(const double *mx, int n, double x) {
 
 /* Everything push_min_pieces needs for merged interval (i1,i2): loads the two pieces and
  * the neighbours it inspects (fpl:876-932), classifies, returns candidates. */
-PSD_D void env_interval_at(const ListView &f1, int n1, const ListView &f2, int n2, int i1, int i2,
-                           Cands &cands, Coef &c1, Coef &c2, int *err) {
+template <class L>
+PSD_D void env_interval_at(const L &f1, int n1, const L &f2, int n2, int i1, int i2, Cands &cands,
+                           Coef &c1, Coef &c2, int &err) {
   c1 = load_coef(f1, i1);
   c2 = load_coef(f2, i2);
-  double mn1 = f1.mn[i1], mx1 = f1.mx[i1], mn2 = f2.mn[i2], mx2 = f2.mx[i2];
+  double mn1 = f1.mn(i1), mx1 = f1.mx(i1), mn2 = f2.mn(i2), mx2 = f2.mx(i2);
   bool same_at_left, same_at_right;
   double last_min_log_mean, first_max_log_mean;
   bool sentinel = false;
@@ -649,30 +702,33 @@ PSD_D void env_interval_at(const ListView &f1, int n1, const ListView &f2, int n
       }
     }
   }
-  bool sentinel_r = false;
   if (mx1 < mx2) {
-    if (i1 + 1 >= n1) sentinel_r = true;
-    same_at_right = !sentinel_r && same_funs(load_coef(f1, i1 + 1), c2);
+    if (i1 + 1 >= n1) sentinel = true;
+    same_at_right = !sentinel && same_funs(load_coef(f1, i1 + 1), c2);
     first_max_log_mean = mx1;
   } else {
     first_max_log_mean = mx2;
     if (mx2 < mx1) {
-      if (i2 + 1 >= n2) sentinel_r = true;
-      same_at_right = !sentinel_r && same_funs(c1, load_coef(f2, i2 + 1));
+      if (i2 + 1 >= n2) sentinel = true;
+      same_at_right = !sentinel && same_funs(c1, load_coef(f2, i2 + 1));
     } else {
       if (i1 + 1 == n1 && i2 + 1 == n2) {
         same_at_right = false;
       } else {
-        if (i1 + 1 >= n1 || i2 + 1 >= n2) sentinel_r = true;
-        same_at_right =
-            !sentinel_r && same_funs(load_coef(f1, i1 + 1), load_coef(f2, i2 + 1));
+        if (i1 + 1 >= n1 || i2 + 1 >= n2) sentinel = true;
+        same_at_right = !sentinel && same_funs(load_coef(f1, i1 + 1), load_coef(f2, i2 + 1));
       }
     }
   }
-  if (sentinel || sentinel_r) *err |= WERR_SENTINEL;
   cands.n = 0;
+  cands.src0 = cands.src1 = cands.src2 = 0;
+  cands.lo0 = cands.hi0 = cands.lo1 = cands.hi1 = cands.lo2 = cands.hi2 = 0.0;
+  if (sentinel) {
+    err |= WERR_SENTINEL;
+    return;
+  }
   if (last_min_log_mean == first_max_log_mean) { /* fpl:933-944 */
-    *err |= WERR_ZERO_INTERVAL;
+    err |= WERR_ZERO_INTERVAL;
     return;
   }
   env_interval(c1, c2, last_min_log_mean, first_max_log_mean, same_at_left, same_at_right,
@@ -691,12 +747,54 @@ PSD_D bool bit_identical(const Coef &last, double last_prv, int last_di, const C
          last_di == di;
 }
 
-/* min-envelope: out = pointwise min(f1, f2).  Returns the piece count.
- * *n_serial is incremented when the sequential replay was needed. */
-PSD_D int min_env_wave(const ListView &f1, int n1, const ListView &f2, int n2,
-                       const ListView &out, int cap, const WaveScratch &s, int iv_cap,
-                       int *n_serial, int *err) {
+/* exact sequential replay of fpl:832-860 + push_piece on lane 0 (cold path) */
+template <class L>
+PSD_NOINLINE int min_env_serial(L f1, int n1, L f2, int n2, L out, int cap, int K) {
   const int lane = lane_id();
+  ScratchStore &s = g_sm.sc[wave_id()];
+  int count = 0;
+  int err = 0;
+  if (lane == 0) {
+    for (int k = 0; k < K && !err; k++) {
+      int e = s.iv[k];
+      int i1 = e >> 16, i2 = e & 0xffff;
+      Cands cd;
+      Coef c1, c2;
+      env_interval_at(f1, n1, f2, n2, i1, i2, cd, c1, c2, err);
+      for (int q = 0; q < cd.n; q++) {
+        int src = q == 0 ? cd.src0 : (q == 1 ? cd.src1 : cd.src2);
+        double lo = q == 0 ? cd.lo0 : (q == 1 ? cd.lo1 : cd.lo2);
+        double hi = q == 0 ? cd.hi0 : (q == 1 ? cd.hi1 : cd.hi2);
+        Coef c = src ? c2 : c1;
+        double prv = src ? f2.prv(i2) : f1.prv(i1);
+        int di = src ? f2.di(i2) : f1.di(i1);
+        if (count > 0 && coalesces(load_coef(out, count - 1), out.prv(count - 1),
+                                   out.di(count - 1), c, prv, di)) {
+          out.mx(count - 1) = hi;
+        } else {
+          if (count >= cap) {
+            err |= WERR_OVERFLOW;
+            break;
+          }
+          store_piece(out, count, c, lo, hi, di, prv);
+          count++;
+        }
+      }
+    }
+  }
+  wave_sync();
+  err = shfl_i(err, 0);
+  count = shfl_i(count, 0);
+  return err ? -err : count;
+}
+
+/* min-envelope: out = pointwise min(f1, f2). */
+template <class L>
+PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap) {
+  const int lane = lane_id();
+  ScratchStore &s = g_sm.sc[wave_id()];
+  const int iv_cap = 2 * LDS_CAP;
+  PSD_PROF_T0();
   /* ---- merged-interval table: interval k ends at the k-th distinct max_log_mean ---- */
   int K;
   {
@@ -707,9 +805,9 @@ PSD_D int min_env_wave(const ListView &f1, int n1, const ListView &f2, int n2,
       int p = 0;
       bool dup = false;
       if (valid) {
-        double x = f1.mx[i];
-        p = lower_bound_mx(f2.mx, n2, x);
-        dup = p < n2 && f2.mx[p] == x;
+        double x = f1.mx(i);
+        p = rank_mx(f2, n2, x);
+        dup = p < n2 && f2.mx(p) == x;
       }
       unsigned long long md = ballot(dup);
       if (valid) {
@@ -726,9 +824,9 @@ PSD_D int min_env_wave(const ListView &f1, int n1, const ListView &f2, int n2,
       int q = 0;
       bool dup = false;
       if (valid) {
-        double x = f2.mx[j];
-        q = lower_bound_mx(f1.mx, n1, x);
-        dup = q < n1 && f1.mx[q] == x;
+        double x = f2.mx(j);
+        q = rank_mx(f1, n1, x);
+        dup = q < n1 && f1.mx(q) == x;
       }
       unsigned long long md = ballot(dup);
       if (valid && !dup) {
@@ -739,14 +837,13 @@ PSD_D int min_env_wave(const ListView &f1, int n1, const ListView &f2, int n2,
     }
     K = n1 + n2 - dup_total;
   }
-  if (K > iv_cap) {
-    *err |= WERR_OVERFLOW;
-    return 0;
-  }
+  if (K > iv_cap || n1 >= 65536 || n2 >= 65536) return -WERR_OVERFLOW;
   wave_sync();
+  PSD_PROF_ADD(PROF_TABLE);
 
   /* ---- one lane per interval; ballot/prefix-scan compaction ---- */
   int n_out = 0;
+  int err = 0;
   bool need_serial = false;
   /* source of the last candidate emitted so far (carried across chunks) */
   Coef last_c = {0.0, 0.0, 0.0};
@@ -758,6 +855,8 @@ PSD_D int min_env_wave(const ListView &f1, int n1, const ListView &f2, int n2,
     bool valid = k < K;
     Cands cd;
     cd.n = 0;
+    cd.src0 = cd.src1 = cd.src2 = 0;
+    cd.lo0 = cd.hi0 = cd.lo1 = cd.hi1 = cd.lo2 = cd.hi2 = 0.0;
     Coef c1 = {0.0, 0.0, 0.0}, c2 = {0.0, 0.0, 0.0};
     double prv1 = 0.0, prv2 = 0.0;
     int di1 = 0, di2 = 0, i1 = 0, i2 = 0;
@@ -766,11 +865,12 @@ PSD_D int min_env_wave(const ListView &f1, int n1, const ListView &f2, int n2,
       i1 = e >> 16;
       i2 = e & 0xffff;
       env_interval_at(f1, n1, f2, n2, i1, i2, cd, c1, c2, err);
-      prv1 = f1.prv[i1];
-      di1 = f1.di[i1];
-      prv2 = f2.prv[i2];
-      di2 = f2.di[i2];
+      prv1 = f1.prv(i1);
+      di1 = f1.di(i1);
+      prv2 = f2.prv(i2);
+      di2 = f2.di(i2);
     }
+    PSD_PROF_ADD(PROF_CLASSIFY);
     /* first / last candidate of this lane */
     Coef fc = cd.src0 ? c2 : c1;
     double fprv = cd.src0 ? prv2 : prv1;
@@ -781,8 +881,15 @@ PSD_D int min_env_wave(const ListView &f1, int n1, const ListView &f2, int n2,
     int ldi = lsrc ? di2 : di1;
     bool has = valid && cd.n > 0;
     unsigned long long m_has = ballot(has);
+    unsigned long long m_err = ballot(err != 0);
+    if (m_err) {
+      int e = 0;
+      for (int l = 0; l < WAVE; l++) e |= shfl_i(err, l);
+      return -e;
+    }
     /* predecessor = last candidate of the nearest lower lane that has one, else carry */
-    unsigned long long below = m_has & lanes_below(lane);
+    unsigned long long lb = lanes_below(lane);
+    unsigned long long below = m_has & lb;
     int psrc = below ? msb64(below) : 0;
     Coef pc;
     pc.Linear = shfl_d(lc.Linear, psrc);
@@ -814,50 +921,33 @@ PSD_D int min_env_wave(const ListView &f1, int n1, const ListView &f2, int n2,
     int heads = has ? ((head0 ? 1 : 0) + (cd.n - 1)) : 0;
     unsigned long long hb0 = ballot((heads & 1) != 0);
     unsigned long long hb1 = ballot((heads & 2) != 0);
-    unsigned long long lb = lanes_below(lane);
     int heads_before = popc64(hb0 & lb) + 2 * popc64(hb1 & lb);
     int heads_total = popc64(hb0) + 2 * popc64(hb1);
-    if (n_out + heads_total > cap) {
-      *err |= WERR_OVERFLOW;
-      return 0;
-    }
+    if (n_out + heads_total > cap) return -WERR_OVERFLOW;
+    int slot = n_out + heads_before - (head0 ? 0 : 1); /* piece candidate 0 belongs to */
     if (has) {
-      /* slot of the piece that candidate 0 belongs to */
-      int slot = n_out + heads_before - (head0 ? 0 : 1);
-      /* is the next candidate (first of the next lane that has one) a head? */
       if (head0) store_piece(out, slot, fc, cd.lo0, cd.hi0, fdi, fprv);
       if (cd.n >= 2) {
-        int sl = slot + 1;
         Coef c = cd.src1 ? c2 : c1;
-        store_piece(out, sl, c, cd.lo1, cd.hi1, cd.src1 ? di2 : di1, cd.src1 ? prv2 : prv1);
+        store_piece(out, slot + 1, c, cd.lo1, cd.hi1, cd.src1 ? di2 : di1,
+                    cd.src1 ? prv2 : prv1);
       }
       if (cd.n >= 3) {
-        int sl = slot + 2;
         Coef c = cd.src2 ? c2 : c1;
-        store_piece(out, sl, c, cd.lo2, cd.hi2, cd.src2 ? di2 : di1, cd.src2 ? prv2 : prv1);
+        store_piece(out, slot + 2, c, cd.lo2, cd.hi2, cd.src2 ? di2 : di1,
+                    cd.src2 ? prv2 : prv1);
       }
     }
     wave_sync();
-    /* a candidate that extends the previous piece only moves its right end; lanes write
-     * in increasing order of hi within a run, and the last one must win: do it after the
-     * heads are in place, lowest lane first is not guaranteed, so only the final member
-     * of each run writes. */
+    /* a candidate that extends the previous piece only moves that piece's right end; of
+     * the members of a run only the last one (in this chunk) writes, after the heads. */
     {
       unsigned long long m_head0 = ballot(has && head0);
       if (has && !head0) {
-        /* this lane's candidate 0 is the last member of its run iff the next lane that
-         * has candidates starts with a head (or there is none in this chunk: then a later
-         * chunk or nobody extends it further, and a later extension overwrites anyway) */
         unsigned long long above = m_has & ~lb & ~(1ull << lane);
         bool next_is_head = true;
-        if (above) {
-          int nl = ctz64(above);
-          next_is_head = ((m_head0 >> nl) & 1ull) != 0;
-        }
-        if (cd.n >= 2 || next_is_head) {
-          int slot = n_out + heads_before - 1;
-          out.mx[slot] = cd.hi0;
-        }
+        if (above) next_is_head = ((m_head0 >> ctz64(above)) & 1ull) != 0;
+        if (cd.n >= 2 || next_is_head) out.mx(slot) = cd.hi0;
       }
     }
     wave_sync();
@@ -871,48 +961,12 @@ PSD_D int min_env_wave(const ListView &f1, int n1, const ListView &f2, int n2,
       last_di = shfl_i(ldi, src);
       have_last = true;
     }
+    PSD_PROF_ADD(PROF_COMPACT);
   }
   if (need_serial) {
-    /* exact sequential replay of fpl:832-860 + push_piece on one lane */
-    (*n_serial)++;
-    int count = 0;
-    int ovf = 0;
-    if (lane == 0) {
-      for (int k = 0; k < K; k++) {
-        int e = s.iv[k];
-        int i1 = e >> 16, i2 = e & 0xffff;
-        Cands cd;
-        Coef c1, c2;
-        env_interval_at(f1, n1, f2, n2, i1, i2, cd, c1, c2, err);
-        for (int q = 0; q < cd.n; q++) {
-          int src = q == 0 ? cd.src0 : (q == 1 ? cd.src1 : cd.src2);
-          double lo = q == 0 ? cd.lo0 : (q == 1 ? cd.lo1 : cd.lo2);
-          double hi = q == 0 ? cd.hi0 : (q == 1 ? cd.hi1 : cd.hi2);
-          Coef c = src ? c2 : c1;
-          double prv = src ? f2.prv[i2] : f1.prv[i1];
-          int di = src ? f2.di[i2] : f1.di[i1];
-          if (count > 0 && coalesces(load_coef(out, count - 1), out.prv[count - 1],
-                                     out.di[count - 1], c, prv, di)) {
-            out.mx[count - 1] = hi;
-          } else {
-            if (count >= cap) {
-              ovf = 1;
-              break;
-            }
-            store_piece(out, count, c, lo, hi, di, prv);
-            count++;
-          }
-        }
-        if (ovf) break;
-      }
-    }
-    wave_sync();
-    ovf = shfl_i(ovf, 0);
-    n_out = shfl_i(count, 0);
-    if (ovf) {
-      *err |= WERR_OVERFLOW;
-      return 0;
-    }
+    if (lane == 0) g_sm.serial[wave_id()]++;
+    n_out = min_env_serial(f1, n1, f2, n2, out, cap, K);
+    PSD_PROF_ADD(PROF_SERIAL);
   }
   return n_out;
 }

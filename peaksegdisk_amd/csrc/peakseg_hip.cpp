@@ -330,6 +330,14 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
     peakseg_hip_problem_set_destroy(s);
     return st;
   }
+#ifdef PSD_PROFILE
+  if ((st = dev_alloc(s, &d.prof, (size_t)n_problems * 2 * psd::N_PROF))) {
+    peakseg_hip_problem_set_destroy(s);
+    return st;
+  }
+#else
+  d.prof = nullptr;
+#endif
   /* arena: the reference's store holds 2 functions per data point with, on typical
    * coverage data, 2-14 pieces each; start at 24 per function and let
    * solve() grow it if a problem reports PST_ARENA_FULL. */
@@ -508,6 +516,22 @@ extern "C" int peakseg_hip_problem_set_export_db(psd_problem_set *s, int p, cons
             fwrite(body.data(), 1, body.size(), f) == body.size();
   ok = fclose(f) == 0 && ok;
   return ok ? 0 : -1;
+}
+
+/* diagnostic builds (-DPSD_PROFILE) only: per-wave cycle counters of the forward kernel */
+extern "C" int peakseg_hip_problem_set_profile(psd_problem_set *s, int p, long long *out) {
+#ifdef PSD_PROFILE
+  if (!s || !s->solved || p < 0 || p >= s->n_problems) return -1;
+  if (hipMemcpy(out, s->d.prof + (size_t)p * 2 * psd::N_PROF, sizeof(long long) * 2 * psd::N_PROF,
+                hipMemcpyDeviceToHost) != hipSuccess)
+    return -1;
+  return psd::N_PROF;
+#else
+  (void)s;
+  (void)p;
+  (void)out;
+  return -1;
+#endif
 }
 
 extern "C" int peakseg_hip_math_probe(int op, int n, const double *x, double *y) {

@@ -17,9 +17,17 @@
 #ifdef PSD_EMU
 #include "hip_emu.h"
 #define PSD_D static inline
+#define PSD_M inline
+#define PSD_NOINLINE static __attribute__((noinline))
+#define PSD_LDS static
 #else
 #include <hip/hip_runtime.h>
 #define PSD_D __device__ __forceinline__
+#define PSD_M __device__ __forceinline__
+/* out-of-line device functions: keeps the forward kernel's hot loop inside the 64 KB
+ * instruction cache (fully inlined it was ~200 KB) */
+#define PSD_NOINLINE __device__ __attribute__((noinline))
+#define PSD_LDS __shared__
 #endif
 
 #include "peakseg_detmath.h"
@@ -57,6 +65,12 @@ PSD_D double uniform_d(double v) {
   uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
   return psd_u2d(((uint64_t)hi << 32) | lo);
 }
+#endif
+
+#ifdef PSD_EMU
+PSD_D long long cycle_now() { return 0; }
+#else
+PSD_D long long cycle_now() { return (long long)__builtin_readcyclecounter(); }
 #endif
 
 PSD_D int popc64(unsigned long long m) { return __builtin_popcountll(m); }

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Diagnostic: build the HIP library with -DPSD_PROFILE (in-kernel cycle stamps around the
+phases of the forward kernel) into gpurun_out/, run a small grid and print, per wave, the share
+of cycles spent in each phase.  Shares only -- a stamped build is slower than the real one.
+
+usage (on the GPU box): python tools/phase_profile.py [bins] [penalties]
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+NAMES = ["pre(costs+classes)", "walk(state machine+roots)", "env table", "env classify",
+         "env compact", "scale_add", "arena", "barrier wait", "env serial", "TOTAL"]
+
+
+def main():
+    bins = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
+    npen = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    lib_path = os.path.join(out, "libpeaksegdisk_hip_prof.so")
+    csrc = os.path.join(ROOT, "peaksegdisk_amd", "csrc")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-x", "hip", "--offload-arch=gfx950", "-O3",
+                    "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DPSD_PROFILE",
+                    "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+                    os.path.join(csrc, "peakseg_hip.cpp"), "-o", lib_path], check=True)
+    from peaksegdisk_amd import _native, synthetic
+    from peaksegdisk_amd.grid import ProblemSet
+    lib = _native.declare(ctypes.CDLL(lib_path))
+    lib.peakseg_hip_problem_set_profile.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    cs, ce, cnt = synthetic.poisson_coverage(bins, seed=1)
+    pens = synthetic.penalty_grid(npen)
+    pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, float(p)) for p in pens], lib=lib)
+    f_ms, b_ms = pset.solve()
+    print("bins=%d penalties=%d forward=%.1f ms backtrack=%.1f ms (stamped build)" % (
+        bins, npen, f_ms, b_ms))
+    for p in range(npen):
+        buf = np.zeros(2 * 12, dtype=np.int64)
+        if lib.peakseg_hip_problem_set_profile(pset._h, p, buf.ctypes.data) < 0:
+            raise SystemExit("profile not available")
+        r = pset.result(p)
+        for w in range(2):
+            v = buf[w * 12:(w + 1) * 12]
+            tot = float(v[9])
+            shares = " ".join("%s=%.1f%%" % (NAMES[i].split("(")[0], 100.0 * v[i] / tot)
+                              for i in range(9))
+            print("pen=%-18s wave%d cyc/step=%7.0f mean_int=%.2f | %s" % (
+                pens[p], w, tot / bins, r.total_intervals / (2.0 * bins), shares))
+    pset.close()
+
+
+if __name__ == "__main__":
+    main()
