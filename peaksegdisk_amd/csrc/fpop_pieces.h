@@ -43,17 +43,8 @@ PSD_D double argmin(const Coef &c) { return d_log(argmin_mean(c)); }
 
 /* fpl:206-222 */
 PSD_D double get_cost(const Coef &c, double log_mean) {
-  double linear_term, log_term;
-  if (log_mean == -PSD_INF) {
-    linear_term = 0.0;
-  } else {
-    linear_term = c.Linear * d_exp(log_mean);
-  }
-  if (c.Log == 0) {
-    log_term = 0.0;
-  } else {
-    log_term = c.Log * log_mean;
-  }
+  double linear_term = (log_mean == -PSD_INF) ? 0.0 : c.Linear * d_exp(log_mean);
+  double log_term = (c.Log == 0) ? 0.0 : c.Log * log_mean;
   return linear_term + log_term + c.Constant;
 }
 
@@ -67,23 +58,49 @@ PSD_D double poisson_loss(const Coef &c, double mean) {
   return loss_without_log_term + product;
 }
 
-/* fpl:29-50; caller guarantees c.Log != 0 (the reference throws otherwise) */
-PSD_D bool has_two_roots(const Coef &c, double equals) {
-  double optimal_mean = argmin_mean(c);
-  double optimal_log_mean = d_log(optimal_mean);
-  double optimal_cost = get_cost(c, optimal_log_mean);
-  double optimal_cost2 = poisson_loss(c, optimal_mean);
-  if (0 < c.Linear) {
-    return optimal_cost + NEWTON_EPSILON < equals && optimal_cost2 + NEWTON_EPSILON < equals;
-  }
-  return equals + NEWTON_EPSILON < optimal_cost && equals + NEWTON_EPSILON < optimal_cost2;
+/* getCost (fpl:206-222) with exp(log_mean) supplied by the caller.  The reference calls libm
+ * again for every evaluation; exp is a pure function of its argument, so re-using a value
+ * already computed for the same argument is exact. */
+PSD_D double get_cost_e(const Coef &c, double log_mean, double exp_log_mean) {
+  double linear_term = (log_mean == -PSD_INF) ? 0.0 : c.Linear * exp_log_mean;
+  double log_term = (c.Log == 0) ? 0.0 : c.Log * log_mean;
+  return linear_term + log_term + c.Constant;
 }
 
-/* fpl:69-127: Newton in mean space from argmin_mean+1; returns the log of the root. */
-PSD_D double get_larger_root(const Coef &c, double max_log_mean, double equals) {
-  double optimal_mean = argmin_mean(c);
-  double optimal_cost = poisson_loss(c, optimal_mean);
-  double right_cost = get_cost(c, max_log_mean);
+/* The optimum of a piece, shared by has_two_roots / get_smaller_root / get_larger_root /
+ * argmin (fpl:37-40,70-71,134-135,203): every one of them starts from the same
+ * argmin_mean(), log(argmin_mean()) and the costs there. */
+struct PieceOpt {
+  double mean;      /* argmin_mean()            = -Log/Linear */
+  double log_mean;  /* argmin()                 = log(mean) */
+  double cost;      /* getCost(log_mean) */
+  double cost2;     /* PoissonLoss(mean)        (uses log(mean) = log_mean) */
+};
+
+PSD_D PieceOpt piece_opt(const Coef &c) {
+  PieceOpt o;
+  o.mean = argmin_mean(c);
+  o.log_mean = d_log(o.mean);
+  o.cost = get_cost(c, o.log_mean);
+  double loss_without_log_term = c.Linear * o.mean + c.Constant; /* fpl:52-61 */
+  o.cost2 = (c.Log == 0) ? loss_without_log_term : loss_without_log_term + o.log_mean * c.Log;
+  return o;
+}
+
+/* fpl:29-50; caller guarantees c.Log != 0 (the reference throws otherwise) */
+PSD_D bool has_two_roots(const Coef &c, const PieceOpt &o, double equals) {
+  if (0 < c.Linear) {
+    return o.cost + NEWTON_EPSILON < equals && o.cost2 + NEWTON_EPSILON < equals;
+  }
+  return equals + NEWTON_EPSILON < o.cost && equals + NEWTON_EPSILON < o.cost2;
+}
+
+/* fpl:69-127: Newton in mean space from argmin_mean+1; returns the log of the root.
+ * right_cost = getCost(max_log_mean), supplied by the caller. */
+PSD_D double get_larger_root(const Coef &c, const PieceOpt &o, double max_log_mean,
+                             double right_cost, double equals) {
+  double optimal_mean = o.mean;
+  double optimal_cost = o.cost2;
   if ((optimal_cost < right_cost && right_cost < equals) ||
       (optimal_cost > right_cost && right_cost > equals)) {
     return max_log_mean + 1;
@@ -100,7 +117,8 @@ PSD_D double get_larger_root(const Coef &c, double max_log_mean, double equals) 
     closest_positive_mean = optimal_mean;
   }
   int step = 0;
-  do {
+  double result_mean;
+  for (;;) {
     candidate_cost = poisson_loss(c, candidate_root) - equals;
     if (0 < candidate_cost && candidate_cost < closest_positive_cost) {
       closest_positive_cost = candidate_cost;
@@ -113,23 +131,25 @@ PSD_D double get_larger_root(const Coef &c, double max_log_mean, double equals) 
     if (NEWTON_STEPS <= ++step) {
       double between_closest = (closest_positive_mean + closest_negative_mean) / 2;
       double between_cost = poisson_loss(c, between_closest) - equals;
-      if (absd(between_cost) < absd(candidate_cost)) {
-        return d_log(between_closest);
-      } else {
-        return d_log(candidate_root);
-      }
+      result_mean = (absd(between_cost) < absd(candidate_cost)) ? between_closest : candidate_root;
+      break;
     }
     deriv = c.Linear + c.Log / candidate_root; /* PoissonDeriv fpl:63-65 */
     candidate_root = candidate_root - candidate_cost / deriv;
-  } while (NEWTON_EPSILON < absd(candidate_cost));
-  return d_log(candidate_root);
+    if (!(NEWTON_EPSILON < absd(candidate_cost))) {
+      result_mean = candidate_root;
+      break;
+    }
+  }
+  return d_log(result_mean);
 }
 
-/* fpl:129-190: Newton in log-mean space from argmin-1. */
-PSD_D double get_smaller_root(const Coef &c, double min_log_mean, double equals) {
-  double optimal_log_mean = argmin(c);
-  double optimal_cost = get_cost(c, optimal_log_mean);
-  double left_cost = get_cost(c, min_log_mean);
+/* fpl:129-190: Newton in log-mean space from argmin-1.
+ * left_cost = getCost(min_log_mean), supplied by the caller. */
+PSD_D double get_smaller_root(const Coef &c, const PieceOpt &o, double min_log_mean,
+                              double left_cost, double equals) {
+  double optimal_log_mean = o.log_mean;
+  double optimal_cost = o.cost;
   if ((equals < left_cost && left_cost < optimal_cost) ||
       (equals > left_cost && left_cost > optimal_cost)) {
     return min_log_mean - 1;
@@ -148,12 +168,7 @@ PSD_D double get_smaller_root(const Coef &c, double min_log_mean, double equals)
   int step = 0;
   do {
     /* getCost and getDeriv (fpl:206-234) evaluate the same Linear*exp(x): once here */
-    double linear_term;
-    if (candidate_root == -PSD_INF) {
-      linear_term = 0.0;
-    } else {
-      linear_term = c.Linear * d_exp(candidate_root);
-    }
+    double linear_term = (candidate_root == -PSD_INF) ? 0.0 : c.Linear * d_exp(candidate_root);
     double log_term = (c.Log == 0) ? 0.0 : c.Log * candidate_root;
     candidate_cost = (linear_term + log_term + c.Constant) - equals;
     if (0 < candidate_cost && candidate_cost < closest_positive_cost) {

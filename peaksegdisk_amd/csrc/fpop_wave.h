@@ -47,11 +47,13 @@ struct ListStore {
 };
 /* per-wave temporaries, one slot per input piece / merged interval */
 struct ScratchStore {
-  double lc[LDS_CAP], rc[LDS_CAP], mu[LDS_CAP], muc[LDS_CAP];
+  double lc[LDS_CAP], rc[LDS_CAP];   /* getCost at the piece's left / right end */
+  double om[LDS_CAP], mu[LDS_CAP];   /* argmin_mean(), argmin() */
+  double muc[LDS_CAP], oc2[LDS_CAP]; /* getCost(argmin()), PoissonLoss(argmin_mean()) */
   int cls[LDS_CAP];
   int iv[2 * LDS_CAP];
 };
-constexpr int N_PROF = 12;
+constexpr int N_PROF = 16;
 /* the workgroup's LDS: lists 0,1 = up (double-buffered), 2,3 = down, 4,5 = per-wave
  * min-less / min-more result */
 struct SharedBlock {
@@ -88,7 +90,9 @@ PSD_LDS SharedBlock g_sm;
 #endif
 enum {
   PROF_PRE = 0, PROF_WALK = 1, PROF_TABLE = 2, PROF_CLASSIFY = 3, PROF_COMPACT = 4,
-  PROF_SCALE = 5, PROF_ARENA = 6, PROF_BARRIER = 7, PROF_SERIAL = 8, PROF_TOTAL = 9
+  PROF_SCALE = 5, PROF_ARENA = 6, PROF_BARRIER = 7, PROF_SERIAL = 8, PROF_TOTAL = 9,
+  PROF_C_LOAD = 10, PROF_C_MID = 11, PROF_C_OPT = 12, PROF_C_SMALL = 13, PROF_C_LARGE = 14,
+  PROF_C_TAIL = 15
 };
 
 /* accessor of an LDS-resident list: g_sm.list[id], elements off.. */
@@ -157,15 +161,14 @@ PSD_D void piece_costs_wave(const L &in, int n, ScratchStore &s) {
       Coef c = load_coef(in, i);
       double lc = get_cost(c, in.mn(i));
       double rc = get_cost(c, in.mx(i));
-      double mu = 0.0, muc = 0.0;
-      if (c.Log != 0) {
-        mu = argmin(c);
-        muc = get_cost(c, mu);
-      }
+      PieceOpt o = {0.0, 0.0, 0.0, 0.0};
+      if (c.Log != 0) o = piece_opt(c);
       s.lc[i] = lc;
       s.rc[i] = rc;
-      s.mu[i] = mu;
-      s.muc[i] = muc;
+      s.om[i] = o.mean;
+      s.mu[i] = o.log_mean;
+      s.muc[i] = o.cost;
+      s.oc2[i] = o.cost2;
     }
   }
   wave_sync();
@@ -285,8 +288,10 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, int data_i_out, doub
         if (c.Log == 0) {
           if (c.Linear < 0) bad = true; /* fpl:378-380 */
         } else {
-          if (has_two_roots(c, prev_min_cost)) {
-            mu = get_smaller_root(c, in.mn(k), prev_min_cost);
+          /* optimum and end costs of piece k were computed in the first pass */
+          PieceOpt o = {s.om[k], s.mu[k], s.muc[k], s.oc2[k]};
+          if (has_two_roots(c, o, prev_min_cost)) {
+            mu = get_smaller_root(c, o, in.mn(k), s.lc[k], prev_min_cost);
             inside = in.mn(k) < mu && mu < in.mx(k);
           }
           if (!inside) at_right = s.rc[k] <= prev_min_cost + NEWTON_EPSILON;
@@ -431,8 +436,9 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, int data_i_out) {
         if (c.Log == 0) {
           mu = d_log((prev_min_cost - c.Constant) / c.Linear); /* fpl:563 */
         } else {
-          if (has_two_roots(c, prev_min_cost)) {
-            mu = get_larger_root(c, in.mx(k), prev_min_cost);
+          PieceOpt o = {s.om[k], s.mu[k], s.muc[k], s.oc2[k]};
+          if (has_two_roots(c, o, prev_min_cost)) {
+            mu = get_larger_root(c, o, in.mx(k), s.rc[k], prev_min_cost);
           }
         }
         inside = in.mn(k) < mu && mu < in.mx(k);
@@ -482,118 +488,124 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, int data_i_out) {
 }
 
 /* ------------------------------------------------------------------------------------- */
-/* candidates emitted for one merged interval: up to three (source, [lo,hi]) in order */
+/* Candidates emitted for one merged interval [a,b].  Every path of push_min_pieces emits
+ * one of three shapes, with the source alternating between the two input pieces:
+ *   n=1: [a,b]            n=2: [a,x1] [x1,b]            n=3: [a,x1] [x1,x2] [x2,b]
+ * `first` is the source of the first piece (0: piece of fun1, 1: piece of fun2).  All split
+ * points are strictly inside (a,b) and ordered (the reference tests that before pushing), so
+ * push_piece's zero-width guard (fpl:1261-1267) can only ever drop the n=1 shape; it is
+ * applied there.  Plain scalars: nothing here is indexed at run time (an indexed struct was
+ * placed in scratch memory by the compiler). */
 struct Cands {
-  int n;
-  int src0, src1, src2; /* 0: piece of fun1, 1: piece of fun2 */
-  double lo0, hi0, lo1, hi1, lo2, hi2;
+  int n, first;
+  double x1, x2;
 };
-
-/* fpl:1261-1267: zero/negative-width pieces are never stored */
-PSD_D void cand_push(Cands &c, int src, double lo, double hi) {
-  if (hi <= lo) return;
-  if (c.n == 0) {
-    c.src0 = src;
-    c.lo0 = lo;
-    c.hi0 = hi;
-  } else if (c.n == 1) {
-    c.src1 = src;
-    c.lo1 = lo;
-    c.hi1 = hi;
-  } else {
-    c.src2 = src;
-    c.lo2 = lo;
-    c.hi2 = hi;
-  }
-  c.n++;
+PSD_D void cand_one(Cands &c, int src, double a, double b) {
+  c.n = (b <= a) ? 0 : 1;
+  c.first = src;
+}
+PSD_D void cand_two(Cands &c, int first, double x) {
+  c.n = 2;
+  c.first = first;
+  c.x1 = x;
+}
+PSD_D void cand_three(Cands &c, int first, double x1, double x2) {
+  c.n = 3;
+  c.first = first;
+  c.x1 = x1;
+  c.x2 = x2;
 }
 
 /* push_min_pieces (fpl:870-1259) for one merged interval [a, b] =
- * [last_min_log_mean, first_max_log_mean] of it1 = c1, it2 = c2. */
+ * [last_min_log_mean, first_max_log_mean] of it1 = c1, it2 = c2.
+ * exp(a), exp(b), the optimum of the difference piece and its end costs are each needed by
+ * several of the reference's helper calls (getCost / has_two_roots / get_*_root / argmin on
+ * the same diff_piece); they are evaluated once here -- identical values, fewer serial
+ * transcendentals. */
 PSD_D void env_interval(const Coef &c1, const Coef &c2, double a, double b, bool same_at_left,
                         bool same_at_right, Cands &out) {
   if (same_funs(c1, c2)) { /* fpl:945-951 */
-    cand_push(out, 0, a, b);
+    cand_one(out, 0, a, b);
     return;
   }
   Coef d;
   d.Linear = c1.Linear - c2.Linear;
   d.Log = c1.Log - c2.Log;
   d.Constant = c1.Constant - c2.Constant;
-  double mid_mean = (d_exp(b) + d_exp(a)) / 2; /* fpl:960 */
+  const double ea = d_exp(a), eb = d_exp(b);
+  double mid_mean = (eb + ea) / 2; /* fpl:960 */
   double cost_diff_mid = get_cost(d, d_log(mid_mean));
   if (same_at_left && same_at_right) { /* fpl:963-971 */
-    cand_push(out, cost_diff_mid < 0 ? 0 : 1, a, b);
+    cand_one(out, cost_diff_mid < 0 ? 0 : 1, a, b);
     return;
   }
   if (d.Log == 0) { /* fpl:973-1019 */
     if (d.Linear == 0) {
-      cand_push(out, d.Constant < 0 ? 0 : 1, a, b);
+      cand_one(out, d.Constant < 0 ? 0 : 1, a, b);
       return;
     }
     if (d.Constant == 0) {
-      cand_push(out, d.Linear < 0 ? 0 : 1, a, b);
+      cand_one(out, d.Linear < 0 ? 0 : 1, a, b);
       return;
     }
     double x = d_log(-d.Constant / d.Linear);
     if (a < x && x < b) {
       int first = (0 < d.Linear) ? 0 : 1;
-      cand_push(out, first, a, x);
-      cand_push(out, 1 - first, x, b);
+      cand_two(out, first, x);
       return;
     }
-    cand_push(out, cost_diff_mid < 0 ? 0 : 1, a, b);
+    cand_one(out, cost_diff_mid < 0 ? 0 : 1, a, b);
     return;
   }
-  double cost_diff_left = get_cost(d, a);
-  double cost_diff_right = get_cost(d, b);
-  bool two_roots = has_two_roots(d, 0.0);
+  double cost_diff_left = get_cost_e(d, a, ea);
+  double cost_diff_right = get_cost_e(d, b, eb);
+  const PieceOpt o = piece_opt(d);
+  bool two_roots = has_two_roots(d, o, 0.0);
   double smaller_log_mean = PSD_INF, larger_log_mean = PSD_INF;
   if (two_roots) {
-    smaller_log_mean = get_smaller_root(d, a, 0.0);
-    larger_log_mean = get_larger_root(d, b, 0.0);
+    smaller_log_mean = get_smaller_root(d, o, a, cost_diff_left, 0.0);
+    larger_log_mean = get_larger_root(d, o, b, cost_diff_right, 0.0);
   }
   if (same_at_right) { /* fpl:1029-1093 */
     if (two_roots) {
       double x = smaller_log_mean;
-      double opt = argmin(d);
+      double opt = o.log_mean; /* diff_piece.argmin() */
       if (a < x && x < opt && opt < b) {
         int first = (cost_diff_left < 0) ? 0 : 1;
-        cand_push(out, first, a, x);
-        cand_push(out, 1 - first, x, b);
+        cand_two(out, first, x);
         return;
       }
       bool it1_smaller_at_mean0 = 0 < d.Log;
       if (x < a) {
-        cand_push(out, it1_smaller_at_mean0 ? 1 : 0, a, b);
+        cand_one(out, it1_smaller_at_mean0 ? 1 : 0, a, b);
       } else {
-        cand_push(out, it1_smaller_at_mean0 ? 0 : 1, a, b);
+        cand_one(out, it1_smaller_at_mean0 ? 0 : 1, a, b);
       }
       return;
     }
-    cand_push(out, cost_diff_mid < 0 ? 0 : 1, a, b);
+    cand_one(out, cost_diff_mid < 0 ? 0 : 1, a, b);
     return;
   }
   if (same_at_left) { /* fpl:1094-1123 */
     if (two_roots) {
       double x = larger_log_mean;
-      double opt = argmin(d);
+      double opt = o.log_mean;
       if (a < opt && opt < x && x < b) {
         int first = (cost_diff_right < 0) ? 1 : 0;
-        cand_push(out, first, a, x);
-        cand_push(out, 1 - first, x, b);
+        cand_two(out, first, x);
         return;
       }
     }
-    cand_push(out, cost_diff_mid < 0 ? 0 : 1, a, b);
+    cand_one(out, cost_diff_mid < 0 ? 0 : 1, a, b);
     return;
   }
   /* equal on neither side (fpl:1124-1258) */
   double first_log_mean = PSD_INF, second_log_mean = PSD_INF;
+  double e_smaller = 0.0;
   if (two_roots) {
     bool larger_inside = a < larger_log_mean && larger_log_mean < b;
-    bool smaller_inside =
-        a < smaller_log_mean && 0 < d_exp(smaller_log_mean) && smaller_log_mean < b;
+    e_smaller = d_exp(smaller_log_mean);
+    bool smaller_inside = a < smaller_log_mean && 0 < e_smaller && smaller_log_mean < b;
     if (larger_inside) {
       if (smaller_inside && smaller_log_mean < larger_log_mean) {
         first_log_mean = smaller_log_mean;
@@ -607,11 +619,29 @@ PSD_D void env_interval(const Coef &c1, const Coef &c2, double a, double b, bool
       }
     }
   }
-  if (second_log_mean != PSD_INF) {
+  if (first_log_mean == PSD_INF) { /* no crossing inside (fpl:1238-1258) */
+    double cost_diff;
+    if (absd(cost_diff_mid) < NEWTON_EPSILON) {
+      cost_diff = cost_diff_right;
+    } else {
+      cost_diff = cost_diff_mid;
+    }
+    cand_one(out, cost_diff < 0 ? 0 : 1, a, b);
+    return;
+  }
+  /* one or two crossings: both cases may test the sign of the difference at the mean-space
+   * midpoint of [a, first crossing] (fpl:1178-1179,1211-1212) */
+  const bool two = second_log_mean != PSD_INF;
+  const bool need_before = !two || (second_log_mean - first_log_mean < first_log_mean - a);
+  double cost_diff_before = 0.0;
+  if (need_before) {
+    double e_first = (first_log_mean == smaller_log_mean) ? e_smaller : d_exp(first_log_mean);
+    double before_mean = (ea + e_first) / 2;
+    cost_diff_before = get_cost(d, d_log(before_mean));
+  }
+  if (two) {
     bool it1_larger_before;
-    if (second_log_mean - first_log_mean < first_log_mean - a) {
-      double before_mean = (d_exp(a) + d_exp(first_log_mean)) / 2;
-      double cost_diff_before = get_cost(d, d_log(before_mean));
+    if (need_before) {
       it1_larger_before = cost_diff_before < 0;
     } else {
       double log_mean_between = (first_log_mean + second_log_mean) / 2;
@@ -619,37 +649,23 @@ PSD_D void env_interval(const Coef &c1, const Coef &c2, double a, double b, bool
       it1_larger_before = !(cost_diff_between < 0);
     }
     int first = it1_larger_before ? 0 : 1;
-    cand_push(out, first, a, first_log_mean);
-    cand_push(out, 1 - first, first_log_mean, second_log_mean);
-    cand_push(out, first, second_log_mean, b);
-  } else if (first_log_mean != PSD_INF) {
-    double before_mean = (d_exp(a) + d_exp(first_log_mean)) / 2;
-    double cost_diff_before = get_cost(d, d_log(before_mean));
+    cand_three(out, first, first_log_mean, second_log_mean);
+  } else {
     double after_mean = (b + first_log_mean) / 2; /* a log-mean, fpl:1216 */
     double cost_diff_after = get_cost(d, after_mean);
     if (cost_diff_before < 0) {
       if (cost_diff_after < 0) {
-        cand_push(out, 0, a, b);
+        cand_one(out, 0, a, b);
       } else {
-        cand_push(out, 0, a, first_log_mean);
-        cand_push(out, 1, first_log_mean, b);
+        cand_two(out, 0, first_log_mean);
       }
     } else {
       if (cost_diff_after < 0) {
-        cand_push(out, 1, a, first_log_mean);
-        cand_push(out, 0, first_log_mean, b);
+        cand_two(out, 1, first_log_mean);
       } else {
-        cand_push(out, 1, a, b);
+        cand_one(out, 1, a, b);
       }
     }
-  } else {
-    double cost_diff;
-    if (absd(cost_diff_mid) < NEWTON_EPSILON) {
-      cost_diff = cost_diff_right;
-    } else {
-      cost_diff = cost_diff_mid;
-    }
-    cand_push(out, cost_diff < 0 ? 0 : 1, a, b);
   }
 }
 
@@ -677,7 +693,7 @@ PSD_D int rank_mx(const L &f, int n, double x) {
  * the neighbours it inspects (fpl:876-932), classifies, returns candidates. */
 template <class L>
 PSD_D void env_interval_at(const L &f1, int n1, const L &f2, int n2, int i1, int i2, Cands &cands,
-                           Coef &c1, Coef &c2, int &err) {
+                           double &a_out, double &b_out, Coef &c1, Coef &c2, int &err) {
   c1 = load_coef(f1, i1);
   c2 = load_coef(f2, i2);
   double mn1 = f1.mn(i1), mx1 = f1.mx(i1), mn2 = f2.mn(i2), mx2 = f2.mx(i2);
@@ -721,8 +737,10 @@ PSD_D void env_interval_at(const L &f1, int n1, const L &f2, int n2, int i1, int
     }
   }
   cands.n = 0;
-  cands.src0 = cands.src1 = cands.src2 = 0;
-  cands.lo0 = cands.hi0 = cands.lo1 = cands.hi1 = cands.lo2 = cands.hi2 = 0.0;
+  cands.first = 0;
+  cands.x1 = cands.x2 = 0.0;
+  a_out = last_min_log_mean;
+  b_out = first_max_log_mean;
   if (sentinel) {
     err |= WERR_SENTINEL;
     return;
@@ -733,6 +751,215 @@ PSD_D void env_interval_at(const L &f1, int n1, const L &f2, int n2, int i1, int
   }
   env_interval(c1, c2, last_min_log_mean, first_max_log_mean, same_at_left, same_at_right,
                cands);
+}
+
+/* The same classification as env_interval(), written for SIMT execution: one lane per merged
+ * interval, and every transcendental evaluation site is reached by all lanes that need it at
+ * the same time (predicated phases) instead of each lane walking its own branch of
+ * push_min_pieces -- a wave otherwise executes the union of all branches one after another.
+ * The arithmetic per lane is identical to env_interval(). */
+PSD_D void env_classify_lanes(bool valid, const Coef &c1, const Coef &c2, double a, double b,
+                              bool same_at_left, bool same_at_right, Cands &out) {
+  out.n = 0;
+  out.first = 0;
+  out.x1 = out.x2 = 0.0;
+  Coef d;
+  d.Linear = c1.Linear - c2.Linear;
+  d.Log = c1.Log - c2.Log;
+  d.Constant = c1.Constant - c2.Constant;
+  const bool triv = same_funs(c1, c2);  /* fpl:945-951 */
+  const bool act = valid && !triv;
+  PSD_PROF_T0();
+  /* phase A/B: exp(a), exp(b), cost at the mean-space midpoint (fpl:960-961) */
+  double ea = 0.0, eb = 0.0, cost_diff_mid = 0.0;
+  if (act) {
+    ea = d_exp(a);
+    eb = d_exp(b);
+    cost_diff_mid = get_cost(d, d_log((eb + ea) / 2));
+  }
+  PSD_PROF_ADD(PROF_C_MID);
+  const bool both = same_at_left && same_at_right;
+  const bool hard = act && !both;
+  const bool degen = hard && d.Log == 0;                              /* fpl:973-1019 */
+  const bool degen_root = degen && d.Linear != 0 && d.Constant != 0;  /* fpl:996 */
+  const bool rootp = hard && d.Log != 0;
+  /* phase C: one log site for the degenerate crossing and for argmin() of the difference */
+  const double larg = degen ? (-d.Constant / d.Linear) : (-d.Log / d.Linear);
+  double lres = 0.0;
+  if (degen_root || rootp) lres = d_log(larg);
+  /* phase D: optimum of the difference piece, its end costs, has_two_roots (fpl:1020-1022) */
+  PieceOpt o = {0.0, 0.0, 0.0, 0.0};
+  double cost_diff_left = 0.0, cost_diff_right = 0.0;
+  bool two_roots = false;
+  if (rootp) {
+    cost_diff_left = get_cost_e(d, a, ea);
+    cost_diff_right = get_cost_e(d, b, eb);
+    o.mean = larg;
+    o.log_mean = lres;
+    o.cost = get_cost(d, lres);
+    double loss_without_log_term = d.Linear * o.mean + d.Constant;
+    o.cost2 = loss_without_log_term + o.log_mean * d.Log;
+    two_roots = has_two_roots(d, o, 0.0);
+  }
+  PSD_PROF_ADD(PROF_C_OPT);
+  /* phases E, F: the two Newton solves (fpl:1023-1028) */
+  double smaller_log_mean = PSD_INF, larger_log_mean = PSD_INF;
+  if (two_roots) smaller_log_mean = get_smaller_root(d, o, a, cost_diff_left, 0.0);
+  PSD_PROF_ADD(PROF_C_SMALL);
+  if (two_roots) larger_log_mean = get_larger_root(d, o, b, cost_diff_right, 0.0);
+  PSD_PROF_ADD(PROF_C_LARGE);
+  /* phase G..: only intervals equal on neither side need more evaluations (fpl:1124-1258) */
+  const bool neither = rootp && !same_at_left && !same_at_right;
+  double e_smaller = 0.0;
+  if (neither && two_roots) e_smaller = d_exp(smaller_log_mean);
+  double first_log_mean = PSD_INF, second_log_mean = PSD_INF;
+  if (neither && two_roots) {
+    bool larger_inside = a < larger_log_mean && larger_log_mean < b;
+    bool smaller_inside = a < smaller_log_mean && 0 < e_smaller && smaller_log_mean < b;
+    if (larger_inside) {
+      if (smaller_inside && smaller_log_mean < larger_log_mean) {
+        first_log_mean = smaller_log_mean;
+        second_log_mean = larger_log_mean;
+      } else {
+        first_log_mean = larger_log_mean;
+      }
+    } else if (smaller_inside) {
+      first_log_mean = smaller_log_mean;
+    }
+  }
+  const bool crossing = neither && first_log_mean != PSD_INF;
+  const bool two = crossing && second_log_mean != PSD_INF;
+  const bool need_before =
+      crossing && (!two || (second_log_mean - first_log_mean < first_log_mean - a));
+  const bool need_other = crossing && !(two && need_before);
+  /* exp(first crossing) unless it is the value already computed */
+  double e_first = e_smaller;
+  if (need_before && first_log_mean != smaller_log_mean) e_first = d_exp(first_log_mean);
+  /* between the crossings (two) or after the crossing (one): both are log-means */
+  const double x_other =
+      two ? (first_log_mean + second_log_mean) / 2 : (b + first_log_mean) / 2;
+  double cost_diff_other = 0.0;
+  if (need_other) cost_diff_other = get_cost(d, x_other);
+  double cost_diff_before = 0.0;
+  if (need_before) cost_diff_before = get_cost(d, d_log((ea + e_first) / 2));
+
+  PSD_PROF_ADD(PROF_C_TAIL);
+  /* ---- decisions (no more transcendentals) ---- */
+  if (!valid) return;
+  const int by_mid = cost_diff_mid < 0 ? 0 : 1;
+  if (triv) {
+    cand_one(out, 0, a, b);
+  } else if (both) { /* fpl:963-971 */
+    cand_one(out, by_mid, a, b);
+  } else if (degen) {
+    if (d.Linear == 0) {
+      cand_one(out, d.Constant < 0 ? 0 : 1, a, b);
+    } else if (d.Constant == 0) {
+      cand_one(out, d.Linear < 0 ? 0 : 1, a, b);
+    } else if (a < lres && lres < b) {
+      cand_two(out, (0 < d.Linear) ? 0 : 1, lres);
+    } else {
+      cand_one(out, by_mid, a, b);
+    }
+  } else if (same_at_right) { /* fpl:1029-1093 */
+    if (two_roots) {
+      double x = smaller_log_mean, opt = o.log_mean;
+      if (a < x && x < opt && opt < b) {
+        cand_two(out, (cost_diff_left < 0) ? 0 : 1, x);
+      } else {
+        bool it1_smaller_at_mean0 = 0 < d.Log;
+        if (x < a) {
+          cand_one(out, it1_smaller_at_mean0 ? 1 : 0, a, b);
+        } else {
+          cand_one(out, it1_smaller_at_mean0 ? 0 : 1, a, b);
+        }
+      }
+    } else {
+      cand_one(out, by_mid, a, b);
+    }
+  } else if (same_at_left) { /* fpl:1094-1123 */
+    double x = larger_log_mean, opt = o.log_mean;
+    if (two_roots && a < opt && opt < x && x < b) {
+      cand_two(out, (cost_diff_right < 0) ? 1 : 0, x);
+    } else {
+      cand_one(out, by_mid, a, b);
+    }
+  } else if (two) { /* fpl:1171-1205 */
+    bool it1_larger_before = need_before ? (cost_diff_before < 0) : !(cost_diff_other < 0);
+    cand_three(out, it1_larger_before ? 0 : 1, first_log_mean, second_log_mean);
+  } else if (crossing) { /* fpl:1206-1237 */
+    if (cost_diff_before < 0) {
+      if (cost_diff_other < 0) {
+        cand_one(out, 0, a, b);
+      } else {
+        cand_two(out, 0, first_log_mean);
+      }
+    } else {
+      if (cost_diff_other < 0) {
+        cand_two(out, 1, first_log_mean);
+      } else {
+        cand_one(out, 1, a, b);
+      }
+    }
+  } else { /* fpl:1238-1258 */
+    double cost_diff;
+    if (absd(cost_diff_mid) < NEWTON_EPSILON) {
+      cost_diff = cost_diff_right;
+    } else {
+      cost_diff = cost_diff_mid;
+    }
+    cand_one(out, cost_diff < 0 ? 0 : 1, a, b);
+  }
+}
+
+/* Loads merged interval (i1,i2): the two pieces, the interval, and the neighbour-equality
+ * flags push_min_pieces derives from the pieces next to them (fpl:876-932). */
+template <class L>
+PSD_D void env_load_interval(const L &f1, int n1, const L &f2, int n2, int i1, int i2, Coef &c1,
+                             Coef &c2, double &a, double &b, bool &same_at_left,
+                             bool &same_at_right, int &err) {
+  c1 = load_coef(f1, i1);
+  c2 = load_coef(f2, i2);
+  double mn1 = f1.mn(i1), mx1 = f1.mx(i1), mn2 = f2.mn(i2), mx2 = f2.mx(i2);
+  bool sentinel = false;
+  if (mn1 < mn2) {
+    if (i2 == 0) sentinel = true;
+    same_at_left = !sentinel && same_funs(load_coef(f2, i2 - 1), c1);
+    a = mn2;
+  } else {
+    a = mn1;
+    if (mn2 < mn1) {
+      if (i1 == 0) sentinel = true;
+      same_at_left = !sentinel && same_funs(load_coef(f1, i1 - 1), c2);
+    } else {
+      if (i1 == 0 && i2 == 0) {
+        same_at_left = false;
+      } else {
+        if (i1 == 0 || i2 == 0) sentinel = true;
+        same_at_left = !sentinel && same_funs(load_coef(f1, i1 - 1), load_coef(f2, i2 - 1));
+      }
+    }
+  }
+  if (mx1 < mx2) {
+    if (i1 + 1 >= n1) sentinel = true;
+    same_at_right = !sentinel && same_funs(load_coef(f1, i1 + 1), c2);
+    b = mx1;
+  } else {
+    b = mx2;
+    if (mx2 < mx1) {
+      if (i2 + 1 >= n2) sentinel = true;
+      same_at_right = !sentinel && same_funs(c1, load_coef(f2, i2 + 1));
+    } else {
+      if (i1 + 1 == n1 && i2 + 1 == n2) {
+        same_at_right = false;
+      } else {
+        if (i1 + 1 >= n1 || i2 + 1 >= n2) sentinel = true;
+        same_at_right = !sentinel && same_funs(load_coef(f1, i1 + 1), load_coef(f2, i2 + 1));
+      }
+    }
+  }
+  if (sentinel) err |= WERR_SENTINEL;
+  if (a == b) err |= WERR_ZERO_INTERVAL; /* fpl:933-944 */
 }
 
 /* push_piece's "same as last" test (fpl:1270-1273) */
@@ -760,11 +987,12 @@ PSD_NOINLINE int min_env_serial(L f1, int n1, L f2, int n2, L out, int cap, int 
       int i1 = e >> 16, i2 = e & 0xffff;
       Cands cd;
       Coef c1, c2;
-      env_interval_at(f1, n1, f2, n2, i1, i2, cd, c1, c2, err);
+      double ia, ib;
+      env_interval_at(f1, n1, f2, n2, i1, i2, cd, ia, ib, c1, c2, err);
       for (int q = 0; q < cd.n; q++) {
-        int src = q == 0 ? cd.src0 : (q == 1 ? cd.src1 : cd.src2);
-        double lo = q == 0 ? cd.lo0 : (q == 1 ? cd.lo1 : cd.lo2);
-        double hi = q == 0 ? cd.hi0 : (q == 1 ? cd.hi1 : cd.hi2);
+        int src = cd.first ^ (q & 1);
+        double lo = q == 0 ? ia : (q == 1 ? cd.x1 : cd.x2);
+        double hi = q == cd.n - 1 ? ib : (q == 0 ? cd.x1 : cd.x2);
         Coef c = src ? c2 : c1;
         double prv = src ? f2.prv(i2) : f1.prv(i1);
         int di = src ? f2.di(i2) : f1.di(i1);
@@ -845,40 +1073,44 @@ PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap) {
   int n_out = 0;
   int err = 0;
   bool need_serial = false;
-  /* source of the last candidate emitted so far (carried across chunks) */
-  Coef last_c = {0.0, 0.0, 0.0};
-  double last_prv = 0.0;
-  int last_di = 0;
-  bool have_last = false;
+  /* source piece of the last candidate emitted so far, (list << 20) | index; carried across
+   * chunks */
+  int last_id = -1;
   for (int base = 0; base < K; base += WAVE) {
     int k = base + lane;
     bool valid = k < K;
     Cands cd;
     cd.n = 0;
-    cd.src0 = cd.src1 = cd.src2 = 0;
-    cd.lo0 = cd.hi0 = cd.lo1 = cd.hi1 = cd.lo2 = cd.hi2 = 0.0;
+    cd.first = 0;
+    cd.x1 = cd.x2 = 0.0;
+    double ia = 0.0, ib = 0.0;
     Coef c1 = {0.0, 0.0, 0.0}, c2 = {0.0, 0.0, 0.0};
     double prv1 = 0.0, prv2 = 0.0;
     int di1 = 0, di2 = 0, i1 = 0, i2 = 0;
+    bool sl = false, sr = false;
+    PSD_PROF_T0();
     if (valid) {
       int e = s.iv[k];
       i1 = e >> 16;
       i2 = e & 0xffff;
-      env_interval_at(f1, n1, f2, n2, i1, i2, cd, c1, c2, err);
+      env_load_interval(f1, n1, f2, n2, i1, i2, c1, c2, ia, ib, sl, sr, err);
       prv1 = f1.prv(i1);
       di1 = f1.di(i1);
       prv2 = f2.prv(i2);
       di2 = f2.di(i2);
     }
+    PSD_PROF_ADD(PROF_C_LOAD);
+    env_classify_lanes(valid && err == 0, c1, c2, ia, ib, sl, sr, cd);
     PSD_PROF_ADD(PROF_CLASSIFY);
     /* first / last candidate of this lane */
-    Coef fc = cd.src0 ? c2 : c1;
-    double fprv = cd.src0 ? prv2 : prv1;
-    int fdi = cd.src0 ? di2 : di1;
-    int lsrc = cd.n == 3 ? cd.src2 : (cd.n == 2 ? cd.src1 : cd.src0);
-    Coef lc = lsrc ? c2 : c1;
-    double lprv = lsrc ? prv2 : prv1;
-    int ldi = lsrc ? di2 : di1;
+    const int src0 = cd.first, src1 = cd.first ^ 1; /* the third piece has source src0 again */
+    Coef fc = src0 ? c2 : c1;
+    double fprv = src0 ? prv2 : prv1;
+    int fdi = src0 ? di2 : di1;
+    int lsrc = cd.n == 2 ? src1 : src0;
+    /* piece q of this interval spans [lo_q, hi_q] */
+    const double hi0 = cd.n == 1 ? ib : cd.x1;
+    const double hi1 = cd.n == 2 ? ib : cd.x2;
     bool has = valid && cd.n > 0;
     unsigned long long m_has = ballot(has);
     unsigned long long m_err = ballot(err != 0);
@@ -887,21 +1119,23 @@ PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap) {
       for (int l = 0; l < WAVE; l++) e |= shfl_i(err, l);
       return -e;
     }
-    /* predecessor = last candidate of the nearest lower lane that has one, else carry */
+    /* predecessor = last candidate of the nearest lower lane that has one, else the carry.
+     * Only its identity crosses lanes; its fields are re-read from the input list. */
     unsigned long long lb = lanes_below(lane);
     unsigned long long below = m_has & lb;
-    int psrc = below ? msb64(below) : 0;
-    Coef pc;
-    pc.Linear = shfl_d(lc.Linear, psrc);
-    pc.Log = shfl_d(lc.Log, psrc);
-    pc.Constant = shfl_d(lc.Constant, psrc);
-    double pprv = shfl_d(lprv, psrc);
-    int pdi = shfl_i(ldi, psrc);
-    bool have_pred = below != 0 || have_last;
-    if (!below) {
-      pc = last_c;
-      pprv = last_prv;
-      pdi = last_di;
+    const int my_last_id = (lsrc << 20) | (lsrc ? i2 : i1);
+    int pid = shfl_i(my_last_id, below ? msb64(below) : 0);
+    if (!below) pid = last_id;
+    const bool have_pred = pid >= 0;
+    Coef pc = {0.0, 0.0, 0.0};
+    double pprv = 0.0;
+    int pdi = 0;
+    if (has && have_pred) {
+      const L &pl = (pid >> 20) ? f2 : f1;
+      const int pi = pid & 0xfffff;
+      pc = load_coef(pl, pi);
+      pprv = pl.prv(pi);
+      pdi = pl.di(pi);
     }
     bool head0 = true; /* does the first candidate start a new output piece? */
     bool fuzzy = false;
@@ -926,17 +1160,12 @@ PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap) {
     if (n_out + heads_total > cap) return -WERR_OVERFLOW;
     int slot = n_out + heads_before - (head0 ? 0 : 1); /* piece candidate 0 belongs to */
     if (has) {
-      if (head0) store_piece(out, slot, fc, cd.lo0, cd.hi0, fdi, fprv);
+      if (head0) store_piece(out, slot, fc, ia, hi0, fdi, fprv);
       if (cd.n >= 2) {
-        Coef c = cd.src1 ? c2 : c1;
-        store_piece(out, slot + 1, c, cd.lo1, cd.hi1, cd.src1 ? di2 : di1,
-                    cd.src1 ? prv2 : prv1);
+        Coef c = src1 ? c2 : c1;
+        store_piece(out, slot + 1, c, cd.x1, hi1, src1 ? di2 : di1, src1 ? prv2 : prv1);
       }
-      if (cd.n >= 3) {
-        Coef c = cd.src2 ? c2 : c1;
-        store_piece(out, slot + 2, c, cd.lo2, cd.hi2, cd.src2 ? di2 : di1,
-                    cd.src2 ? prv2 : prv1);
-      }
+      if (cd.n >= 3) store_piece(out, slot + 2, fc, cd.x2, ib, fdi, fprv);
     }
     wave_sync();
     /* a candidate that extends the previous piece only moves that piece's right end; of
@@ -947,20 +1176,12 @@ PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap) {
         unsigned long long above = m_has & ~lb & ~(1ull << lane);
         bool next_is_head = true;
         if (above) next_is_head = ((m_head0 >> ctz64(above)) & 1ull) != 0;
-        if (cd.n >= 2 || next_is_head) out.mx(slot) = cd.hi0;
+        if (cd.n >= 2 || next_is_head) out.mx(slot) = hi0;
       }
     }
     wave_sync();
     n_out += heads_total;
-    if (m_has) {
-      int src = msb64(m_has);
-      last_c.Linear = shfl_d(lc.Linear, src);
-      last_c.Log = shfl_d(lc.Log, src);
-      last_c.Constant = shfl_d(lc.Constant, src);
-      last_prv = shfl_d(lprv, src);
-      last_di = shfl_i(ldi, src);
-      have_last = true;
-    }
+    if (m_has) last_id = shfl_i(my_last_id, msb64(m_has));
     PSD_PROF_ADD(PROF_COMPACT);
   }
   if (need_serial) {

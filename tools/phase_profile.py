@@ -15,7 +15,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 NAMES = ["pre(costs+classes)", "walk(state machine+roots)", "env table", "env classify",
-         "env compact", "scale_add", "arena", "barrier wait", "env serial", "TOTAL"]
+         "env compact", "scale_add", "arena", "barrier wait", "env serial", "TOTAL",
+         "c.load", "c.mid", "c.opt", "c.small", "c.large", "c.tail"]
+NP = 16
 
 
 def main():
@@ -40,15 +42,15 @@ def main():
     print("bins=%d penalties=%d forward=%.1f ms backtrack=%.1f ms (stamped build)" % (
         bins, npen, f_ms, b_ms))
     for p in range(npen):
-        buf = np.zeros(2 * 12, dtype=np.int64)
+        buf = np.zeros(2 * NP, dtype=np.int64)
         if lib.peakseg_hip_problem_set_profile(pset._h, p, buf.ctypes.data) < 0:
             raise SystemExit("profile not available")
         r = pset.result(p)
         for w in range(2):
-            v = buf[w * 12:(w + 1) * 12]
+            v = buf[w * NP:(w + 1) * NP]
             tot = float(v[9])
             shares = " ".join("%s=%.1f%%" % (NAMES[i].split("(")[0], 100.0 * v[i] / tot)
-                              for i in range(9))
+                              for i in list(range(9)) + list(range(10, NP)))
             print("pen=%-18s wave%d cyc/step=%7.0f mean_int=%.2f | %s" % (
                 pens[p], w, tot / bins, r.total_intervals / (2.0 * bins), shares))
     pset.close()
