@@ -74,6 +74,7 @@ typedef struct {
   double best_cost;       /* mean penalized cost (loss.tsv column 6) */
   int n_serial_env;       /* diagnostics: min-envelope calls replayed sequentially */
   int step_reached;
+  int spill_steps;        /* data points processed with the piece lists spilled to HBM */
 } psd_result;
 
 int peakseg_hip_device_count(void);

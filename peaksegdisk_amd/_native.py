@@ -27,6 +27,7 @@ class PsdResult(ctypes.Structure):
         ("best_cost", ctypes.c_double),
         ("n_serial_env", ctypes.c_int),
         ("step_reached", ctypes.c_int),
+        ("spill_steps", ctypes.c_int),
     ]
 
 

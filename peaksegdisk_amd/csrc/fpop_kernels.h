@@ -52,6 +52,7 @@ struct ProbResult {
   int n_equality;         /* drv:411,436 */
   int n_serial_env;       /* min-envelope calls that needed the sequential replay */
   int step_reached;
+  int spill_steps;        /* data points processed with the lists in the HBM spill area */
 };
 
 struct DeviceArgs {
@@ -80,7 +81,42 @@ struct DeviceArgs {
   int *seg_start;   /* data index whose chromEnd starts the segment; -1 = first_chromStart */
   double *seg_mean; /* exp(best_log_mean) */
   long long *prof;  /* PSD_PROFILE builds: per (problem, wave) cycle counters, else NULL */
+  /* spill area for functions with more than LDS_CAP pieces: per problem 48*spill_cap doubles
+   * (6 lists x 6 fields + 2 waves x 6 scratch arrays) and 12*spill_cap ints */
+  double *spill_f64;
+  int *spill_i32;
+  int spill_cap;
 };
+
+PSD_D GlobalList global_list(const DeviceArgs &a, int p, int id) {
+  const size_t cap = (size_t)a.spill_cap;
+  double *f = a.spill_f64 + ((size_t)p * 48 + (size_t)id * 6) * cap;
+  GlobalList r;
+  r.Lin_ = f;
+  r.Log_ = f + cap;
+  r.Con_ = f + 2 * cap;
+  r.mn_ = f + 3 * cap;
+  r.mx_ = f + 4 * cap;
+  r.prv_ = f + 5 * cap;
+  r.di_ = a.spill_i32 + ((size_t)p * 12 + (size_t)id) * cap;
+  return r;
+}
+PSD_D GlobalScratch global_scratch(const DeviceArgs &a, int p, int wave) {
+  const size_t cap = (size_t)a.spill_cap;
+  double *f = a.spill_f64 + ((size_t)p * 48 + 36 + (size_t)wave * 6) * cap;
+  int *q = a.spill_i32 + ((size_t)p * 12 + 6) * cap;
+  GlobalScratch r;
+  r.lc_ = f;
+  r.rc_ = f + cap;
+  r.om_ = f + 2 * cap;
+  r.mu_ = f + 3 * cap;
+  r.muc_ = f + 4 * cap;
+  r.oc2_ = f + 5 * cap;
+  r.cls_ = q + (size_t)wave * cap;
+  r.iv_ = q + 2 * cap + (size_t)wave * 2 * cap;
+  r.iv_cap_ = 2 * a.spill_cap;
+  return r;
+}
 
 /* f <- (f * cum_weight_prev + (weight, -coverage*weight, 0)) * (1/cum_weight)
  * exactly as drv:316-321 / 365-370: multiply, add, multiply, no contraction. */
@@ -192,8 +228,61 @@ PSD_D void minimize_wave(const L &f, int n, double *best_cost, double *best_log_
   *prev_log_mean = bprv;
 }
 
-/* list ids in g_sm.list[]: 2*chain + buffer for the two cost functions (chain 0 = up,
- * 1 = down), 4 + chain for the chain's min-less / min-more temporary */
+template <class LS, class LD>
+PSD_D void copy_list_across(const LS &src, int n, const LD &dst) {
+  const int lane = lane_id();
+  for (int base = 0; base < n; base += WAVE) {
+    int i = base + lane;
+    if (i < n)
+      store_piece(dst, i, load_coef(src, i), src.mn(i), src.mx(i), src.di(i), src.prv(i));
+  }
+}
+
+/* One chain's update for data point t >= 1 (chain 0: up_t, chain 1: down_t):
+ *   up_t   = min_env(min_less(down_{t-1}) + penalty/W_{t-1}, up_{t-1})   drv:273-300
+ *   down_t = min_env(min_more(up_{t-1}),                    down_{t-1})  drv:324-349
+ *   (t == 1: up_1 = the min-less result, down_1 = down_0)
+ * then multiply, add the data point, multiply (drv:316-321,365-370).
+ * Returns the new piece count or -(WERR_* bits). */
+template <class L, class S>
+PSD_D int chain_step(int chain, int t, const L &other_prev, int n_other, const L &own_prev,
+                     int n_own, const L &own_new, const L &mlist, const S &sc, int cap,
+                     double pen_term, double cum_weight_prev, double w, int coverage,
+                     double cum_weight) {
+  int nm = 0;
+  if (chain == 0) {
+    nm = min_less_wave(other_prev, n_other, mlist, cap, sc, t - 1, pen_term);
+  } else if (t >= 2) {
+    nm = min_more_wave(other_prev, n_other, mlist, cap, sc, t - 1);
+  }
+  if (nm < 0) return nm;
+  int n_new;
+  if (t == 1) {
+    if (chain == 0) {
+      copy_list_wave(mlist, nm, own_new);
+      n_new = nm;
+    } else {
+      copy_list_wave(own_prev, n_own, own_new);
+      n_new = n_own;
+    }
+  } else {
+    const L f1 = chain == 0 ? mlist : mlist.shifted(cap - nm);
+    n_new = min_env_wave(f1, nm, own_prev, n_own, own_new, cap, sc);
+  }
+  if (n_new < 0) return n_new;
+  PSD_PROF_T0();
+  wave_sync();
+  scale_add_wave(own_new, n_new, cum_weight_prev, w, (double)(-coverage) * w, 1 / cum_weight);
+  wave_sync();
+  PSD_PROF_ADD(PROF_SCALE);
+  return n_new;
+}
+
+/* list ids: 2*chain + buffer for the two cost functions (chain 0 = up, 1 = down), 4 + chain
+ * for the chain's min-less / min-more temporary.  Lists live in LDS (g_sm.list[id]) while
+ * every function has at most LDS_CAP pieces; when an operation overflows, the step is redone
+ * with all lists in the HBM spill area, and the problem returns to LDS once both functions
+ * have shrunk below LDS_CAP/2. */
 __global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
   const int p = (int)blockIdx.x;
   const int chain = wave_id();
@@ -206,10 +295,12 @@ __global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
   const unsigned long long fn0 =
       (unsigned long long)a.prob_fn_off[p] + (chain == 1 ? (unsigned long long)N : 0ull);
   const LdsList mlist = lds_list(4 + chain);
+  LdsScratch lsc;
+  lsc.w = chain;
 
   if (threadIdx.x == 0) {
-    g_sm.abort_status[0] = g_sm.abort_status[1] = 0;
-    g_sm.abort_err[0] = g_sm.abort_err[1] = 0;
+    g_sm.abort_status[0] = g_sm.abort_status[1] = g_sm.abort_status[2] = 0;
+    g_sm.abort_err[0] = g_sm.abort_err[1] = g_sm.abort_err[2] = 0;
     for (int i = 0; i < 6; i++) g_sm.n[i] = 0;
     g_sm.serial[0] = g_sm.serial[1] = 0;
 #ifdef PSD_PROFILE
@@ -224,11 +315,14 @@ __global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
   cur.room = 0;
   unsigned long long total_intervals = 0;
   int max_intervals = 0;
+  int spill_steps = 0;
   int status = 0;
   double cum_weight_i = 0.0, cum_weight_prev_i = -1.0;
   int cnt_reg = 0, wt_reg = 0;
-  int b = 0; /* buffer holding step t-1 */
+  int b = 0;        /* buffer holding step t-1 */
+  bool in_hbm = false; /* where the lists of step t-1 live */
   int t = 0;
+  unsigned sync_no = 0; /* parity slot of the abort flags: one per barrier */
 #ifdef PSD_PROFILE
   long long t_begin = cycle_now();
 #endif
@@ -241,89 +335,85 @@ __global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
     }
     const int coverage = shfl_i(cnt_reg, t & 63);
     const double w = (double)shfl_i(wt_reg, t & 63);
-    cum_weight_i += w;
+    const double cum_weight_new = cum_weight_i + w;
     const int nb = b ^ 1;
-    const LdsList own_prev = lds_list(2 * chain + b);
-    const LdsList own_new = lds_list(2 * chain + nb);
-    const LdsList other_prev = lds_list(2 * (1 - chain) + b);
-    const int n_own = uniform_i(g_sm.n[own_prev.id]);
-    const int n_other = uniform_i(g_sm.n[other_prev.id]);
-    int n_new = 0;
-    if (t == 0) {
-      /* C^down_1 = gamma_1 / w_1 (drv:266-270); there is no up function yet */
-      if (chain == 1) {
-        if (lane == 0) {
-          Coef c;
-          c.Linear = 1.0;
-          c.Log = (double)(-coverage);
-          c.Constant = 0.0;
-          store_piece(own_new, 0, c, a.contig_min_log_mean[contig],
-                      a.contig_max_log_mean[contig], -1, -5.0);
-        }
-        n_new = 1;
-      }
-    } else {
-      /* up_t   = min_env(min_less(down_{t-1}) + penalty/W_{t-1}, up_{t-1})   drv:273-300
-       * down_t = min_env(min_more(up_{t-1}),                    down_{t-1})  drv:324-349
-       * (t == 1: up_1 = the min-less result, down_1 = down_0) */
-      int nm = 0;
-      if (chain == 0) {
-        nm = min_less_wave(other_prev, n_other, mlist, LDS_CAP, t - 1,
-                           penalty / cum_weight_prev_i);
-      } else if (t >= 2) {
-        nm = min_more_wave(other_prev, n_other, mlist, LDS_CAP, t - 1);
-      }
-      if (nm >= 0) {
-        if (t == 1) {
-          if (chain == 0) {
-            copy_list_wave(mlist, nm, own_new);
-            n_new = nm;
-          } else {
-            copy_list_wave(own_prev, n_own, own_new);
-            n_new = n_own;
-          }
-        } else {
-          const LdsList f1 = chain == 0 ? mlist : mlist.shifted(LDS_CAP - nm);
-          n_new = min_env_wave(f1, nm, own_prev, n_own, own_new, LDS_CAP);
-        }
-      } else {
-        n_new = nm;
-      }
-      if (n_new >= 0) {
-        PSD_PROF_T0();
-        wave_sync();
-        /* then multiply, add the data point, multiply (drv:316-321,365-370) */
-        scale_add_wave(own_new, n_new, cum_weight_prev_i, w, (double)(-coverage) * w,
-                       1 / cum_weight_i);
-        wave_sync();
-        PSD_PROF_ADD(PROF_SCALE);
-      }
+    const int id_own_prev = 2 * chain + b, id_own_new = 2 * chain + nb;
+    const int id_other_prev = 2 * (1 - chain) + b;
+    const int n_own = uniform_i(g_sm.n[id_own_prev]);
+    const int n_other = uniform_i(g_sm.n[id_other_prev]);
+    /* come back from HBM when both functions fit comfortably again */
+    if (in_hbm && n_own <= LDS_CAP / 2 && n_other <= LDS_CAP / 2) {
+      copy_list_across(global_list(a, p, id_own_prev), n_own, lds_list(id_own_prev));
+      in_hbm = false;
+      __syncthreads();
     }
-    /* ---- end of step: publish sizes, commit the backtrack record ---- */
-    {
+    int n_new = 0;
+    for (;;) { /* at most two passes: LDS, then HBM after an overflow */
+      if (t == 0) {
+        /* C^down_1 = gamma_1 / w_1 (drv:266-270); there is no up function yet */
+        if (chain == 1) {
+          if (lane == 0) {
+            Coef c;
+            c.Linear = 1.0;
+            c.Log = (double)(-coverage);
+            c.Constant = 0.0;
+            store_piece(lds_list(id_own_new), 0, c, a.contig_min_log_mean[contig],
+                        a.contig_max_log_mean[contig], -1, -5.0);
+          }
+          n_new = 1;
+        }
+      } else if (!in_hbm) {
+        n_new = chain_step(chain, t, lds_list(id_other_prev), n_other, lds_list(id_own_prev),
+                           n_own, lds_list(id_own_new), mlist, lsc, LDS_CAP,
+                           penalty / cum_weight_prev_i, cum_weight_prev_i, w, coverage,
+                           cum_weight_new);
+      } else {
+        n_new = chain_step(chain, t, global_list(a, p, id_other_prev), n_other,
+                           global_list(a, p, id_own_prev), n_own, global_list(a, p, id_own_new),
+                           global_list(a, p, 4 + chain), global_scratch(a, p, chain),
+                           a.spill_cap, penalty / cum_weight_prev_i, cum_weight_prev_i, w,
+                           coverage, cum_weight_new);
+      }
+      /* ---- end of pass: report, store the backtrack record, meet the other wave ---- */
       PSD_PROF_T0();
+      const unsigned slot = sync_no % 3u;
+      if (lane == 0) g_sm.n[id_own_new] = n_new < 0 ? 0 : n_new;
       if (n_new < 0) {
         if (lane == 0) {
-          g_sm.abort_err[t & 1] = -n_new;
-          g_sm.abort_status[t & 1] = ((-n_new) & WERR_OVERFLOW) ? PST_LDS_OVERFLOW : PST_REF_THROW;
+          g_sm.abort_err[slot] = -n_new;
+          g_sm.abort_status[slot] =
+              ((-n_new) & WERR_OVERFLOW) ? PST_LDS_OVERFLOW : PST_REF_THROW;
         }
-        n_new = 0;
       } else if (chain == 1 || t > 0) {
-        if (!arena_store_wave(a, cur, own_new, n_new, fn0 + (unsigned long long)t)) {
-          if (lane == 0) g_sm.abort_status[t & 1] = PST_ARENA_FULL;
-        }
+        bool ok = in_hbm ? arena_store_wave(a, cur, global_list(a, p, id_own_new), n_new,
+                                            fn0 + (unsigned long long)t)
+                         : arena_store_wave(a, cur, lds_list(id_own_new), n_new,
+                                            fn0 + (unsigned long long)t);
+        if (!ok && lane == 0) g_sm.abort_status[slot] = PST_ARENA_FULL;
       }
-      if (lane == 0) g_sm.n[own_new.id] = n_new;
       PSD_PROF_ADD(PROF_ARENA);
-      total_intervals += (unsigned long long)n_new;
-      if (max_intervals < n_new) max_intervals = n_new;
-      cum_weight_prev_i = cum_weight_i;
       __syncthreads();
       PSD_PROF_ADD(PROF_BARRIER);
+      status = uniform_i(g_sm.abort_status[slot]);
+      /* three rotating slots: the one cleared here is first written two barriers later */
+      if (lane == 0) g_sm.abort_status[(sync_no + 2u) % 3u] = 0;
+      sync_no++;
+      if (status == PST_LDS_OVERFLOW && !in_hbm && a.spill_cap > LDS_CAP && t > 0) {
+        /* redo this data point with the lists in HBM: every wave moves its own t-1 list */
+        copy_list_across(lds_list(id_own_prev), n_own, global_list(a, p, id_own_prev));
+        in_hbm = true;
+        status = 0;
+        __syncthreads();
+        continue;
+      }
+      break;
     }
-    status = uniform_i(g_sm.abort_status[t & 1]);
     if (status != 0) break;
-    if (lane == 0) g_sm.abort_status[(t + 1) & 1] = 0;
+    total_intervals += (unsigned long long)n_new;
+    if (max_intervals < n_new) max_intervals = n_new;
+    if (in_hbm) spill_steps++;
+    cum_weight_i = cum_weight_new;
+    cum_weight_prev_i = cum_weight_i;
     b = nb;
   }
   /* ---- after the last data point: Minimize the final down function (drv:404-406) ---- */
@@ -346,17 +436,23 @@ __global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
     r.prev_log_mean = 0.0;
     r.prev_seg_end = -1;
     r.status = status;
-    r.wave_err = g_sm.abort_err[0] | g_sm.abort_err[1];
+    r.wave_err = g_sm.abort_err[0] | g_sm.abort_err[1] | g_sm.abort_err[2];
     r.max_intervals = max_intervals > g_sm.max_up ? max_intervals : g_sm.max_up;
     r.total_intervals = total_intervals + g_sm.total_up;
     r.n_segments = 0;
     r.n_equality = 0;
     r.n_serial_env = g_sm.serial[0] + g_sm.serial[1];
     r.step_reached = t;
+    r.spill_steps = spill_steps;
     if (status == 0) {
       const int id = 2 + b;
-      minimize_wave(lds_list(id), g_sm.n[id], &r.best_cost, &r.best_log_mean, &r.prev_seg_end,
-                    &r.prev_log_mean);
+      if (in_hbm) {
+        minimize_wave(global_list(a, p, id), g_sm.n[id], &r.best_cost, &r.best_log_mean,
+                      &r.prev_seg_end, &r.prev_log_mean);
+      } else {
+        minimize_wave(lds_list(id), g_sm.n[id], &r.best_cost, &r.best_log_mean, &r.prev_seg_end,
+                      &r.prev_log_mean);
+      }
     }
     if (lane == 0) a.result[p] = r;
   }

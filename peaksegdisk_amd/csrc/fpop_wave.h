@@ -60,8 +60,8 @@ struct SharedBlock {
   ListStore list[6];
   ScratchStore sc[2];
   int n[6];
-  int abort_status[2];
-  int abort_err[2];
+  int abort_status[3];
+  int abort_err[3];
   unsigned long long total_up;
   int max_up;
   int serial[2];
@@ -112,6 +112,59 @@ struct LdsList {
     return r;
   }
 };
+/* accessor of a wave's LDS scratch arrays */
+struct LdsScratch {
+  int w;
+  PSD_M double &lc(int i) const { return g_sm.sc[w].lc[i]; }
+  PSD_M double &rc(int i) const { return g_sm.sc[w].rc[i]; }
+  PSD_M double &om(int i) const { return g_sm.sc[w].om[i]; }
+  PSD_M double &mu(int i) const { return g_sm.sc[w].mu[i]; }
+  PSD_M double &muc(int i) const { return g_sm.sc[w].muc[i]; }
+  PSD_M double &oc2(int i) const { return g_sm.sc[w].oc2[i]; }
+  PSD_M int &cls(int i) const { return g_sm.sc[w].cls[i]; }
+  PSD_M int &iv(int i) const { return g_sm.sc[w].iv[i]; }
+  PSD_M int iv_cap() const { return 2 * LDS_CAP; }
+};
+
+/* The same two accessors over HBM: the spill path for functions with more than LDS_CAP
+ * pieces (adversarial data, vignettes/Worst_case.Rmd).  `cap` pieces per list. */
+struct GlobalList {
+  double *Lin_, *Log_, *Con_, *mn_, *mx_, *prv_;
+  int *di_;
+  PSD_M double &Lin(int i) const { return Lin_[i]; }
+  PSD_M double &Log(int i) const { return Log_[i]; }
+  PSD_M double &Con(int i) const { return Con_[i]; }
+  PSD_M double &mn(int i) const { return mn_[i]; }
+  PSD_M double &mx(int i) const { return mx_[i]; }
+  PSD_M double &prv(int i) const { return prv_[i]; }
+  PSD_M int &di(int i) const { return di_[i]; }
+  PSD_M GlobalList shifted(int d) const {
+    GlobalList r;
+    r.Lin_ = Lin_ + d;
+    r.Log_ = Log_ + d;
+    r.Con_ = Con_ + d;
+    r.mn_ = mn_ + d;
+    r.mx_ = mx_ + d;
+    r.prv_ = prv_ + d;
+    r.di_ = di_ + d;
+    return r;
+  }
+};
+struct GlobalScratch {
+  double *lc_, *rc_, *om_, *mu_, *muc_, *oc2_;
+  int *cls_, *iv_;
+  int iv_cap_;
+  PSD_M double &lc(int i) const { return lc_[i]; }
+  PSD_M double &rc(int i) const { return rc_[i]; }
+  PSD_M double &om(int i) const { return om_[i]; }
+  PSD_M double &mu(int i) const { return mu_[i]; }
+  PSD_M double &muc(int i) const { return muc_[i]; }
+  PSD_M double &oc2(int i) const { return oc2_[i]; }
+  PSD_M int &cls(int i) const { return cls_[i]; }
+  PSD_M int &iv(int i) const { return iv_[i]; }
+  PSD_M int iv_cap() const { return iv_cap_; }
+};
+
 PSD_D LdsList lds_list(int id) {
   LdsList r;
   r.id = id;
@@ -152,8 +205,8 @@ enum {
 
 /* Shared first half of min-less / min-more: per piece, the costs at both ends, the argmin
  * and its cost (fpl:245-246,310-311 / 469-470,483-485). */
-template <class L>
-PSD_D void piece_costs_wave(const L &in, int n, ScratchStore &s) {
+template <class L, class S>
+PSD_D void piece_costs_wave(const L &in, int n, const S &s) {
   const int lane = lane_id();
   for (int base = 0; base < n; base += WAVE) {
     int i = base + lane;
@@ -163,12 +216,12 @@ PSD_D void piece_costs_wave(const L &in, int n, ScratchStore &s) {
       double rc = get_cost(c, in.mx(i));
       PieceOpt o = {0.0, 0.0, 0.0, 0.0};
       if (c.Log != 0) o = piece_opt(c);
-      s.lc[i] = lc;
-      s.rc[i] = rc;
-      s.om[i] = o.mean;
-      s.mu[i] = o.log_mean;
-      s.muc[i] = o.cost;
-      s.oc2[i] = o.cost2;
+      s.lc(i) = lc;
+      s.rc(i) = rc;
+      s.om(i) = o.mean;
+      s.mu(i) = o.log_mean;
+      s.muc(i) = o.cost;
+      s.oc2(i) = o.cost2;
     }
   }
   wave_sync();
@@ -178,10 +231,10 @@ PSD_D void piece_costs_wave(const L &in, int n, ScratchStore &s) {
 /* min-less: out(x) = min_{y<=x} in(y).  All output pieces get data_i = data_i_out (the
  * driver's set_prev_seg_end) and Constant += add_const (its add(0,0,penalty/cum_weight_prev),
  * PeakSegFPOPLog.cpp:290-296). */
-template <class L>
-PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, int data_i_out, double add_const) {
+template <class L, class S>
+PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
+                               double add_const) {
   const int lane = lane_id();
-  ScratchStore &s = g_sm.sc[wave_id()];
   PSD_PROF_T0();
   piece_costs_wave(in, n, s);
   /* what the walk does with piece i when it reaches it in search mode */
@@ -189,9 +242,9 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, int data_i_out, doub
     int i = base + lane;
     if (i < n) {
       double Log_i = in.Log(i);
-      double lc = s.lc[i], rc = s.rc[i];
+      double lc = s.lc(i), rc = s.rc(i);
       bool has_next = i + 1 < n;
-      double next_left_cost = has_next ? s.lc[i + 1] : PSD_INF;
+      double next_left_cost = has_next ? s.lc(i + 1) : PSD_INF;
       int cls;
       if (Log_i == 0) { /* fpl:256-308 */
         double right_left_diff = rc - lc;
@@ -203,7 +256,7 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, int data_i_out, doub
         }
         cls = (next_cost_more_than_left && !right_left_equal) ? CLS_CONST_EDGE : CLS_STORE;
       } else { /* fpl:309-366 */
-        double mu = s.mu[i], mu_cost = s.muc[i];
+        double mu = s.mu(i), mu_cost = s.muc(i);
         bool next_ok = true;
         if (has_next) next_ok = NEWTON_EPSILON < next_left_cost - mu_cost;
         bool cost_ok = NEWTON_EPSILON < rc - mu_cost && next_ok;
@@ -215,7 +268,7 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, int data_i_out, doub
           cls = CLS_STORE;
         }
       }
-      s.cls[i] = cls;
+      s.cls(i) = cls;
     }
   }
   wave_sync();
@@ -230,7 +283,7 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, int data_i_out, doub
     int j = n;
     for (int base = i0 & ~(WAVE - 1); base < n; base += WAVE) {
       int i = base + lane;
-      bool hit = i >= i0 && i < n && s.cls[i] != CLS_STORE;
+      bool hit = i >= i0 && i < n && s.cls(i) != CLS_STORE;
       unsigned long long m = ballot(hit);
       if (m) {
         j = base + ctz64(m);
@@ -256,8 +309,8 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, int data_i_out, doub
     if (j == n) break;
     /* ---- piece j starts a constant piece ---- */
     double prev_min_cost, prev_best_log_mean;
-    if (s.cls[j] == CLS_CONST_MU) { /* fpl:337-355 */
-      double mu = s.mu[j];
+    if (s.cls(j) == CLS_CONST_MU) { /* fpl:337-355 */
+      double mu = s.mu(j);
       if (prev_min_log_mean < mu) {
         if (lane == 0) {
           Coef c = load_coef(in, j);
@@ -270,9 +323,9 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, int data_i_out, doub
       }
       prev_min_log_mean = mu;
       prev_best_log_mean = mu;
-      prev_min_cost = s.muc[j];
+      prev_min_cost = s.muc(j);
     } else { /* fpl:288-292,328-336 */
-      prev_min_cost = s.lc[j];
+      prev_min_cost = s.lc(j);
       prev_best_log_mean = in.mn(j);
     }
     /* ---- constant mode: first piece k > j where the constant ends (fpl:367-422) ---- */
@@ -289,12 +342,12 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, int data_i_out, doub
           if (c.Linear < 0) bad = true; /* fpl:378-380 */
         } else {
           /* optimum and end costs of piece k were computed in the first pass */
-          PieceOpt o = {s.om[k], s.mu[k], s.muc[k], s.oc2[k]};
+          PieceOpt o = {s.om(k), s.mu(k), s.muc(k), s.oc2(k)};
           if (has_two_roots(c, o, prev_min_cost)) {
-            mu = get_smaller_root(c, o, in.mn(k), s.lc[k], prev_min_cost);
+            mu = get_smaller_root(c, o, in.mn(k), s.lc(k), prev_min_cost);
             inside = in.mn(k) < mu && mu < in.mx(k);
           }
-          if (!inside) at_right = s.rc[k] <= prev_min_cost + NEWTON_EPSILON;
+          if (!inside) at_right = s.rc(k) <= prev_min_cost + NEWTON_EPSILON;
         }
       }
       unsigned long long m_ev = ballot(inside || at_right);
@@ -344,10 +397,9 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, int data_i_out, doub
 /* ------------------------------------------------------------------------------------- */
 /* min-more: out(x) = min_{y>=x} in(y).  The reference builds the list with emplace_front;
  * here pieces are written downwards from out[cap-1]: the result is out[cap-n .. cap). */
-template <class L>
-PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, int data_i_out) {
+template <class L, class S>
+PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, S s, int data_i_out) {
   const int lane = lane_id();
-  ScratchStore &s = g_sm.sc[wave_id()];
   PSD_PROF_T0();
   piece_costs_wave(in, n, s);
   for (int base = 0; base < n; base += WAVE) {
@@ -357,15 +409,15 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, int data_i_out) {
       if (in.Log(i) == 0) { /* fpl:458-467 */
         cls = CLS_STORE;
       } else { /* fpl:468-548 */
-        double mu = s.mu[i], mu_cost = s.muc[i];
+        double mu = s.mu(i), mu_cost = s.muc(i);
         bool prev_ok = true;
         if (i > 0) {
-          double prev_cost_right = s.rc[i - 1];
+          double prev_cost_right = s.rc(i - 1);
           prev_ok = NEWTON_EPSILON < prev_cost_right - mu_cost;
         }
-        double this_cost_left = s.lc[i];
+        double this_cost_left = s.lc(i);
         if (in.mx(i) <= mu) {
-          double this_cost_diff = this_cost_left - s.rc[i];
+          double this_cost_diff = this_cost_left - s.rc(i);
           cls = (NEWTON_EPSILON < this_cost_diff) ? CLS_CONST_EDGE : CLS_STORE;
         } else if (in.mn(i) < mu && NEWTON_EPSILON < this_cost_left - mu_cost && prev_ok) {
           cls = CLS_CONST_MU;
@@ -373,7 +425,7 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, int data_i_out) {
           cls = CLS_STORE;
         }
       }
-      s.cls[i] = cls;
+      s.cls(i) = cls;
     }
   }
   wave_sync();
@@ -387,7 +439,7 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, int data_i_out) {
     int j = -1;
     for (int base = i0 | (WAVE - 1); base >= 0; base -= WAVE) { /* base = top of a chunk */
       int i = base - lane;
-      bool hit = i <= i0 && i >= 0 && s.cls[i] != CLS_STORE;
+      bool hit = i <= i0 && i >= 0 && s.cls(i) != CLS_STORE;
       unsigned long long m = ballot(hit);
       if (m) {
         j = base - ctz64(m);
@@ -408,8 +460,8 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, int data_i_out) {
     if (cnt > 0) prev_max_log_mean = in.mn(j + 1);
     if (j < 0) break;
     double prev_min_cost, prev_best_log_mean;
-    if (s.cls[j] == CLS_CONST_MU) { /* fpl:524-537 */
-      double mu = s.mu[j];
+    if (s.cls(j) == CLS_CONST_MU) { /* fpl:524-537 */
+      double mu = s.mu(j);
       if (mu < prev_max_log_mean) {
         if (lane == 0)
           store_piece(out, cap - 1 - n_out, load_coef(in, j), mu, prev_max_log_mean, data_i_out,
@@ -418,9 +470,9 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, int data_i_out) {
       }
       prev_max_log_mean = mu;
       prev_best_log_mean = mu;
-      prev_min_cost = s.muc[j];
+      prev_min_cost = s.muc(j);
     } else { /* fpl:500-510 */
-      prev_min_cost = s.rc[j];
+      prev_min_cost = s.rc(j);
       prev_best_log_mean = in.mx(j);
     }
     /* ---- constant mode: highest piece k < j where the constant ends (fpl:549-602) ---- */
@@ -436,13 +488,13 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, int data_i_out) {
         if (c.Log == 0) {
           mu = d_log((prev_min_cost - c.Constant) / c.Linear); /* fpl:563 */
         } else {
-          PieceOpt o = {s.om[k], s.mu[k], s.muc[k], s.oc2[k]};
+          PieceOpt o = {s.om(k), s.mu(k), s.muc(k), s.oc2(k)};
           if (has_two_roots(c, o, prev_min_cost)) {
-            mu = get_larger_root(c, o, in.mx(k), s.rc[k], prev_min_cost);
+            mu = get_larger_root(c, o, in.mx(k), s.rc(k), prev_min_cost);
           }
         }
         inside = in.mn(k) < mu && mu < in.mx(k);
-        if (!inside) at_left = s.lc[k] <= prev_min_cost + NEWTON_EPSILON;
+        if (!inside) at_left = s.lc(k) <= prev_min_cost + NEWTON_EPSILON;
       }
       unsigned long long m_ev = ballot(inside || at_left);
       if (m_ev) {
@@ -975,15 +1027,14 @@ PSD_D bool bit_identical(const Coef &last, double last_prv, int last_di, const C
 }
 
 /* exact sequential replay of fpl:832-860 + push_piece on lane 0 (cold path) */
-template <class L>
-PSD_NOINLINE int min_env_serial(L f1, int n1, L f2, int n2, L out, int cap, int K) {
+template <class L, class S>
+PSD_NOINLINE int min_env_serial(L f1, int n1, L f2, int n2, L out, int cap, S s, int K) {
   const int lane = lane_id();
-  ScratchStore &s = g_sm.sc[wave_id()];
   int count = 0;
   int err = 0;
   if (lane == 0) {
     for (int k = 0; k < K && !err; k++) {
-      int e = s.iv[k];
+      int e = s.iv(k);
       int i1 = e >> 16, i2 = e & 0xffff;
       Cands cd;
       Coef c1, c2;
@@ -1017,11 +1068,10 @@ PSD_NOINLINE int min_env_serial(L f1, int n1, L f2, int n2, L out, int cap, int 
 }
 
 /* min-envelope: out = pointwise min(f1, f2). */
-template <class L>
-PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap) {
+template <class L, class S>
+PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap, S s) {
   const int lane = lane_id();
-  ScratchStore &s = g_sm.sc[wave_id()];
-  const int iv_cap = 2 * LDS_CAP;
+  const int iv_cap = s.iv_cap();
   PSD_PROF_T0();
   /* ---- merged-interval table: interval k ends at the k-th distinct max_log_mean ---- */
   int K;
@@ -1040,7 +1090,7 @@ PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap) {
       unsigned long long md = ballot(dup);
       if (valid) {
         int k = i + p - (dup_before + popc64(md & lanes_below(lane)));
-        if (k < iv_cap) s.iv[k] = (i << 16) | p;
+        if (k < iv_cap) s.iv(k) = (i << 16) | p;
       }
       dup_before += popc64(md);
     }
@@ -1059,7 +1109,7 @@ PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap) {
       unsigned long long md = ballot(dup);
       if (valid && !dup) {
         int k = j + q - (dup_before + popc64(md & lanes_below(lane)));
-        if (k < iv_cap) s.iv[k] = (q << 16) | j;
+        if (k < iv_cap) s.iv(k) = (q << 16) | j;
       }
       dup_before += popc64(md);
     }
@@ -1090,7 +1140,7 @@ PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap) {
     bool sl = false, sr = false;
     PSD_PROF_T0();
     if (valid) {
-      int e = s.iv[k];
+      int e = s.iv(k);
       i1 = e >> 16;
       i2 = e & 0xffff;
       env_load_interval(f1, n1, f2, n2, i1, i2, c1, c2, ia, ib, sl, sr, err);
@@ -1186,7 +1236,7 @@ PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap) {
   }
   if (need_serial) {
     if (lane == 0) g_sm.serial[wave_id()]++;
-    n_out = min_env_serial(f1, n1, f2, n2, out, cap, K);
+    n_out = min_env_serial(f1, n1, f2, n2, out, cap, s, K);
     PSD_PROF_ADD(PROF_SERIAL);
   }
   return n_out;

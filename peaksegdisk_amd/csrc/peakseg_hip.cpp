@@ -330,6 +330,22 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
     peakseg_hip_problem_set_destroy(s);
     return st;
   }
+  /* spill area for functions that outgrow LDS (adversarial data): PEAKSEG_HIP_SPILL_CAP pieces
+   * per list, default 16384 (432 bytes per piece per problem); 0 disables spilling */
+  {
+    int cap = 16384;
+    if (const char *e = getenv("PEAKSEG_HIP_SPILL_CAP")) cap = atoi(e);
+    if (cap > 65535) cap = 65535;
+    if (cap <= psd::LDS_CAP) cap = 0;
+    d.spill_cap = cap;
+    d.spill_f64 = nullptr;
+    d.spill_i32 = nullptr;
+    if (cap > 0 && ((st = dev_alloc(s, &d.spill_f64, (size_t)n_problems * 48 * (size_t)cap)) ||
+                    (st = dev_alloc(s, &d.spill_i32, (size_t)n_problems * 12 * (size_t)cap)))) {
+      peakseg_hip_problem_set_destroy(s);
+      return st;
+    }
+  }
 #ifdef PSD_PROFILE
   if ((st = dev_alloc(s, &d.prof, (size_t)n_problems * 2 * psd::N_PROF))) {
     peakseg_hip_problem_set_destroy(s);
@@ -437,6 +453,7 @@ extern "C" int peakseg_hip_problem_set_result(psd_problem_set *s, int p, psd_res
   out->best_cost = r.best_cost;
   out->n_serial_env = r.n_serial_env;
   out->step_reached = r.step_reached;
+  out->spill_steps = r.spill_steps;
   return 0;
 }
 

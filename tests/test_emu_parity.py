@@ -57,3 +57,7 @@ def test_emu_synthetic(psd, oracle_det, oracle_libm, tmp_path):
 
 def test_emu_python_entry_points(psd, tmp_path):
     gp.test_python_entry_points(psd, tmp_path)
+
+
+def test_emu_adversarial_spill(psd, oracle_det, tmp_path):
+    gp.test_adversarial_increasing_counts_spill(psd, oracle_det, tmp_path, 1500)

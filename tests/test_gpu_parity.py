@@ -206,3 +206,39 @@ def test_python_entry_points(psd, tmp_path):
     assert int(fit.loss["peaks"].iloc[0]) == 19
     assert list(fit.others["peaks"]) == [3199, 0, 224, 17, 74, 35, 25, 21, 18, 20, 19] or \
         sorted(fit.others["peaks"]) == sorted([3199, 0, 224, 17, 74, 35, 25, 21, 18, 20, 19])
+
+
+@GPU
+@pytest.mark.parametrize("n_bins", [4000])
+def test_adversarial_increasing_counts_spill(psd, oracle_det, tmp_path, n_bins):
+    """vignettes/Worst_case.Rmd:26-28: count = 1..N makes the piece lists grow far beyond the
+    128 pieces that fit in LDS, so the HBM spill path (and the way back to LDS) is exercised;
+    results must still equal the oracle's byte for byte, including every stored function."""
+    from peaksegdisk_amd import ProblemSet, synthetic
+    cs, ce, cnt = synthetic.increasing_coverage(n_bins)
+    pens = ["100", "0", "10000"]
+    pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, float(p)) for p in pens])
+    pset.solve()
+    bg = str(tmp_path / "coverage.bedGraph")
+    synthetic.write_bedgraph(bg, cs, ce, cnt)
+    spilled = 0
+    for i, pen in enumerate(pens):
+        r = pset.result(i)
+        assert r.status == 0
+        spilled += r.spill_steps
+        db_o = str(tmp_path / ("oracle_%d.db" % i))
+        assert oracle_det.solve(bg, pen, db_o) == 0
+        loss = read_loss("%s_penalty=%s_loss.tsv" % (bg, pen)).split("\t")
+        assert int(loss[1]) == r.n_segments
+        assert float(loss[9]) == r.max_intervals
+        assert float(loss[8]) == r.total_intervals / (2.0 * n_bins)
+        db_g = str(tmp_path / ("gpu_%d.db" % i))
+        pset.export_db(i, ce, db_g)
+        assert open(db_g, "rb").read() == open(db_o, "rb").read(), pen
+        start, mean = pset.segments(i)
+        segs = read_segments("%s_penalty=%s_segments.bed" % (bg, pen))
+        assert len(segs) == len(start)
+        assert [s[1] for s in segs] == [0 if k < 0 else int(ce[k]) for k in start]
+    assert spilled > 0, "test did not reach the spill path"
+    assert pset.result(0).max_intervals > 128
+    pset.close()
