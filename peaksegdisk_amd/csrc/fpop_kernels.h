@@ -298,6 +298,7 @@ __global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
   LdsScratch lsc;
   lsc.w = chain;
 
+  psd_tables_init(); /* exp/log tables -> LDS */
   if (threadIdx.x == 0) {
     g_sm.abort_status[0] = g_sm.abort_status[1] = g_sm.abort_status[2] = 0;
     g_sm.abort_err[0] = g_sm.abort_err[1] = g_sm.abort_err[2] = 0;
@@ -462,6 +463,7 @@ __global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
 __global__ __launch_bounds__(64) void fpop_backtrack_kernel(DeviceArgs a) {
   const int p = (int)blockIdx.x;
   const int lane = lane_id();
+  psd_tables_init(); /* exp/log tables -> LDS (segment means are exp(log-mean)) */
   ProbResult r = a.result[p];
   if (r.status != 0) return;
   const int N = a.contig_n[a.prob_contig[p]];
@@ -534,6 +536,7 @@ __global__ __launch_bounds__(64) void fpop_backtrack_kernel(DeviceArgs a) {
 }
 
 __global__ void math_probe_kernel(int op, int n, const double *x, double *y) {
+  psd_tables_init();
   int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (i < n) y[i] = op == 0 ? d_exp(x[i]) : d_log(x[i]);
 }

@@ -9,6 +9,7 @@
 
 __global__ void probe(double *out, long long *cyc, double seed) {
   __shared__ double lds[256];
+  psd_tables_init();
   int lane = threadIdx.x;
   double x = seed + lane * 1e-3;
   long long t0, t1;
