@@ -203,17 +203,31 @@ enum {
   WERR_ZERO_INTERVAL = 8, /* fpl:933 zero-size merged interval */
 };
 
-/* Shared first half of min-less / min-more: per piece, the costs at both ends, the argmin
- * and its cost (fpl:245-246,310-311 / 469-470,483-485). */
+/* A lane's own copy of piece `lane` and of what the first pass computed for it (functions of
+ * at most 64 pieces): the walk's state machine then reads other pieces with v_readlane
+ * instead of dependent LDS round trips. */
+struct LanePiece {
+  Coef c;
+  double mn, mx;
+  double lc, rc;   /* getCost at the left / right end */
+  double om, mu;   /* argmin_mean(), argmin() */
+  double muc, oc2; /* getCost(argmin()), PoissonLoss(argmin_mean()) */
+  int cls;
+};
+
+/* Shared first half of min-less / min-more: per piece, the costs at both ends and the
+ * optimum (fpl:245-246,310-311 / 469-470,483-485); kept in scratch for every piece and in
+ * registers for piece `lane`. */
 template <class L, class S>
-PSD_D void piece_costs_wave(const L &in, int n, const S &s) {
+PSD_D void piece_costs_wave(const L &in, int n, const S &s, LanePiece &P) {
   const int lane = lane_id();
   for (int base = 0; base < n; base += WAVE) {
     int i = base + lane;
     if (i < n) {
       Coef c = load_coef(in, i);
-      double lc = get_cost(c, in.mn(i));
-      double rc = get_cost(c, in.mx(i));
+      double mn = in.mn(i), mx = in.mx(i);
+      double lc = get_cost(c, mn);
+      double rc = get_cost(c, mx);
       PieceOpt o = {0.0, 0.0, 0.0, 0.0};
       if (c.Log != 0) o = piece_opt(c);
       s.lc(i) = lc;
@@ -222,6 +236,17 @@ PSD_D void piece_costs_wave(const L &in, int n, const S &s) {
       s.mu(i) = o.log_mean;
       s.muc(i) = o.cost;
       s.oc2(i) = o.cost2;
+      if (base == 0) {
+        P.c = c;
+        P.mn = mn;
+        P.mx = mx;
+        P.lc = lc;
+        P.rc = rc;
+        P.om = o.mean;
+        P.mu = o.log_mean;
+        P.muc = o.cost;
+        P.oc2 = o.cost2;
+      }
     }
   }
   wave_sync();
@@ -235,8 +260,13 @@ template <class L, class S>
 PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
                                double add_const) {
   const int lane = lane_id();
+  const bool small = n <= WAVE; /* lane i holds piece i */
+  LanePiece P;
+  P.c.Linear = P.c.Log = P.c.Constant = 0.0;
+  P.mn = P.mx = P.lc = P.rc = P.om = P.mu = P.muc = P.oc2 = 0.0;
+  P.cls = CLS_STORE;
   PSD_PROF_T0();
-  piece_costs_wave(in, n, s);
+  piece_costs_wave(in, n, s, P);
   /* what the walk does with piece i when it reaches it in search mode */
   for (int base = 0; base < n; base += WAVE) {
     int i = base + lane;
@@ -269,21 +299,77 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
         }
       }
       s.cls(i) = cls;
+      if (base == 0) P.cls = cls;
     }
   }
   wave_sync();
   PSD_PROF_ADD(PROF_PRE);
+  /* uniform reads of piece j: registers of lane j when the function fits one wave */
+  auto cls_at = [&](int j) -> int { return small ? rdlane_i(P.cls, j) : s.cls(j); };
+  auto mu_at = [&](int j) -> double { return small ? rdlane_d(P.mu, j) : s.mu(j); };
+  auto muc_at = [&](int j) -> double { return small ? rdlane_d(P.muc, j) : s.muc(j); };
+  auto lc_at = [&](int j) -> double { return small ? rdlane_d(P.lc, j) : s.lc(j); };
+  auto mn_at = [&](int j) -> double { return small ? rdlane_d(P.mn, j) : in.mn(j); };
+  auto mx_at = [&](int j) -> double { return small ? rdlane_d(P.mx, j) : in.mx(j); };
 
   int err = 0;
+  /* ---- all-pairs speculation ------------------------------------------------------------
+   * Where the constant started at piece j ends depends only on j (its level c_j is known from
+   * the first pass) and on the pieces after it, not on how the walk got to j.  When all
+   * (start j, later piece k) pairs fit in one wave, every pair tests its crossing NOW, in one
+   * round of Newton solves, and the walk below only looks results up.  Otherwise each
+   * constant scans its remaining pieces when the walk reaches it (one round per constant). */
+  bool spec = false;
+  unsigned long long sp_ev = 0, sp_inside = 0, sp_bad = 0;
+  double sp_mu = PSD_INF;
+  int my_base = 0; /* lane j: first task lane of start j */
+  if (small) {
+    unsigned long long m_start = ballot(lane < n && P.cls != CLS_STORE);
+    int total = 0;
+    for (unsigned long long m = m_start; m; m &= m - 1) total += n - 1 - ctz64(m);
+    if (total > 0 && total <= WAVE) {
+      spec = true;
+      int tj = -1, tk = 0, base = 0;
+      for (unsigned long long m = m_start; m; m &= m - 1) {
+        int j = ctz64(m), cnt = n - 1 - j;
+        if (lane == j) my_base = base;
+        if (lane >= base && lane < base + cnt) {
+          tj = j;
+          tk = j + 1 + (lane - base);
+        }
+        base += cnt;
+      }
+      bool inside = false, at_right = false, bad = false;
+      if (tj >= 0) {
+        double level = (s.cls(tj) == CLS_CONST_MU) ? s.muc(tj) : s.lc(tj);
+        Coef c = load_coef(in, tk);
+        if (c.Log == 0) {
+          if (c.Linear < 0) bad = true; /* fpl:378-380 */
+        } else {
+          PieceOpt o = {s.om(tk), s.mu(tk), s.muc(tk), s.oc2(tk)};
+          if (has_two_roots(c, o, level)) {
+            sp_mu = get_smaller_root(c, o, in.mn(tk), s.lc(tk), level);
+            inside = in.mn(tk) < sp_mu && sp_mu < in.mx(tk);
+          }
+          if (!inside) at_right = s.rc(tk) <= level + NEWTON_EPSILON;
+        }
+      }
+      sp_ev = ballot(inside || at_right);
+      sp_inside = ballot(inside);
+      sp_bad = ballot(bad);
+    }
+  }
+  PSD_PROF_ADD(PROF_SERIAL); /* diagnostic builds: the speculation round */
   int n_out = 0;
   int i0 = 0;
-  double prev_min_log_mean = in.mn(0);
+  double prev_min_log_mean = mn_at(0);
   for (;;) {
     /* ---- search mode: first piece j >= i0 that starts a constant ---- */
     int j = n;
     for (int base = i0 & ~(WAVE - 1); base < n; base += WAVE) {
       int i = base + lane;
-      bool hit = i >= i0 && i < n && s.cls(i) != CLS_STORE;
+      int cls_i = small ? P.cls : ((i < n) ? s.cls(i) : CLS_STORE);
+      bool hit = i >= i0 && i < n && cls_i != CLS_STORE;
       unsigned long long m = ballot(hit);
       if (m) {
         j = base + ctz64(m);
@@ -293,24 +379,26 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
     /* pieces i0..j-1 are kept as they are (fpl:303-307,361-364) */
     int cnt = j - i0;
     if (n_out + cnt + 2 > cap) return -WERR_OVERFLOW;
-    for (int base = i0; base < j; base += WAVE) {
-      int i = base + lane;
-      if (i < j) {
-        Coef c = load_coef(in, i);
+    for (int base = i0; base < j; base += (small ? n : WAVE)) {
+      int i = small ? lane : base + lane;
+      if (i >= i0 && i < j) {
+        Coef c = small ? P.c : load_coef(in, i);
         c.Constant = c.Constant + add_const;
         c.Linear = c.Linear + 0.0;
         c.Log = c.Log + 0.0;
-        double lo = (i == i0) ? prev_min_log_mean : in.mn(i);
-        store_piece(out, n_out + (i - i0), c, lo, in.mx(i), data_i_out, PSD_INF);
+        double mn_i = small ? P.mn : in.mn(i);
+        double mx_i = small ? P.mx : in.mx(i);
+        double lo = (i == i0) ? prev_min_log_mean : mn_i;
+        store_piece(out, n_out + (i - i0), c, lo, mx_i, data_i_out, PSD_INF);
       }
     }
     n_out += cnt;
-    if (cnt > 0) prev_min_log_mean = in.mx(j - 1);
+    if (cnt > 0) prev_min_log_mean = mx_at(j - 1);
     if (j == n) break;
     /* ---- piece j starts a constant piece ---- */
     double prev_min_cost, prev_best_log_mean;
-    if (s.cls(j) == CLS_CONST_MU) { /* fpl:337-355 */
-      double mu = s.mu(j);
+    if (cls_at(j) == CLS_CONST_MU) { /* fpl:337-355 */
+      double mu = mu_at(j);
       if (prev_min_log_mean < mu) {
         if (lane == 0) {
           Coef c = load_coef(in, j);
@@ -323,43 +411,61 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
       }
       prev_min_log_mean = mu;
       prev_best_log_mean = mu;
-      prev_min_cost = s.muc(j);
+      prev_min_cost = muc_at(j);
     } else { /* fpl:288-292,328-336 */
-      prev_min_cost = s.lc(j);
-      prev_best_log_mean = in.mn(j);
+      prev_min_cost = lc_at(j);
+      prev_best_log_mean = mn_at(j);
     }
     /* ---- constant mode: first piece k > j where the constant ends (fpl:367-422) ---- */
     int k_ev = -1;
     bool ev_inside = false;
     double ev_mu = 0.0;
-    for (int base = j + 1; base < n; base += WAVE) {
-      int k = base + lane;
-      bool inside = false, at_right = false, bad = false;
-      double mu = PSD_INF;
-      if (k < n) {
-        Coef c = load_coef(in, k);
-        if (c.Log == 0) {
-          if (c.Linear < 0) bad = true; /* fpl:378-380 */
-        } else {
-          /* optimum and end costs of piece k were computed in the first pass */
-          PieceOpt o = {s.om(k), s.mu(k), s.muc(k), s.oc2(k)};
-          if (has_two_roots(c, o, prev_min_cost)) {
-            mu = get_smaller_root(c, o, in.mn(k), s.lc(k), prev_min_cost);
-            inside = in.mn(k) < mu && mu < in.mx(k);
-          }
-          if (!inside) at_right = s.rc(k) <= prev_min_cost + NEWTON_EPSILON;
+    if (spec) {
+      int cntj = n - 1 - j;
+      if (cntj > 0) {
+        int base = rdlane_i(my_base, j);
+        unsigned long long range = (cntj >= 64 ? ~0ull : ((1ull << cntj) - 1ull)) << base;
+        unsigned long long ev = sp_ev & range;
+        unsigned long long visited = ev ? (range & lanes_below(ctz64(ev))) : range;
+        if (sp_bad & visited) err |= WERR_REF_THROW;
+        if (ev) {
+          int src = ctz64(ev);
+          k_ev = j + 1 + (src - base);
+          ev_inside = ((sp_inside >> src) & 1ull) != 0;
+          ev_mu = rdlane_d(sp_mu, src);
         }
       }
-      unsigned long long m_ev = ballot(inside || at_right);
-      unsigned long long m_bad = ballot(bad);
-      unsigned long long visited = m_ev ? lanes_below(ctz64(m_ev)) : ~0ull;
-      if (m_bad & visited) err |= WERR_REF_THROW;
-      if (m_ev) {
-        int src = ctz64(m_ev);
-        k_ev = base + src;
-        ev_inside = shfl_i(inside ? 1 : 0, src) != 0;
-        ev_mu = shfl_d(mu, src);
-        break;
+    } else {
+      for (int base = j + 1; base < n; base += WAVE) {
+        int k = base + lane;
+        bool inside = false, at_right = false, bad = false;
+        double mu = PSD_INF;
+        if (k < n) {
+          Coef c = load_coef(in, k);
+          if (c.Log == 0) {
+            if (c.Linear < 0) bad = true; /* fpl:378-380 */
+          } else {
+            /* optimum and end costs of piece k were computed in the first pass */
+            PieceOpt o = {s.om(k), s.mu(k), s.muc(k), s.oc2(k)};
+            if (has_two_roots(c, o, prev_min_cost)) {
+              mu = get_smaller_root(c, o, in.mn(k), s.lc(k), prev_min_cost);
+              inside = in.mn(k) < mu && mu < in.mx(k);
+            }
+            if (!inside) at_right = s.rc(k) <= prev_min_cost + NEWTON_EPSILON;
+          }
+        }
+        unsigned long long m_ev = ballot(inside || at_right);
+        unsigned long long m_in = ballot(inside);
+        unsigned long long m_bad = ballot(bad);
+        unsigned long long visited = m_ev ? lanes_below(ctz64(m_ev)) : ~0ull;
+        if (m_bad & visited) err |= WERR_REF_THROW;
+        if (m_ev) {
+          int src = ctz64(m_ev);
+          k_ev = base + src;
+          ev_inside = ((m_in >> src) & 1ull) != 0;
+          ev_mu = rdlane_d(mu, src);
+          break;
+        }
       }
     }
     Coef cc;
@@ -367,8 +473,9 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
     cc.Log = 0.0 + 0.0;
     cc.Constant = prev_min_cost + add_const;
     if (k_ev < 0) { /* constant runs to the end (fpl:429-436) */
+      double mx_last = mx_at(n - 1);
       if (lane == 0)
-        store_piece(out, n_out, cc, prev_min_log_mean, in.mx(n - 1), data_i_out,
+        store_piece(out, n_out, cc, prev_min_log_mean, mx_last, data_i_out,
                     prev_best_log_mean);
       n_out++;
       break;
@@ -380,7 +487,7 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
       prev_min_log_mean = ev_mu;
       i0 = k_ev;
     } else { /* constant ends on the right end of piece k (fpl:410-420) */
-      double mxk = in.mx(k_ev);
+      double mxk = mx_at(k_ev);
       if (lane == 0)
         store_piece(out, n_out, cc, prev_min_log_mean, mxk, data_i_out, prev_best_log_mean);
       n_out++;
@@ -400,8 +507,13 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
 template <class L, class S>
 PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, S s, int data_i_out) {
   const int lane = lane_id();
+  const bool small = n <= WAVE;
+  LanePiece P;
+  P.c.Linear = P.c.Log = P.c.Constant = 0.0;
+  P.mn = P.mx = P.lc = P.rc = P.om = P.mu = P.muc = P.oc2 = 0.0;
+  P.cls = CLS_STORE;
   PSD_PROF_T0();
-  piece_costs_wave(in, n, s);
+  piece_costs_wave(in, n, s, P);
   for (int base = 0; base < n; base += WAVE) {
     int i = base + lane;
     if (i < n) {
@@ -426,42 +538,98 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, S s, int data_i_out)
         }
       }
       s.cls(i) = cls;
+      if (base == 0) P.cls = cls;
     }
   }
   wave_sync();
   PSD_PROF_ADD(PROF_PRE);
+  auto cls_at = [&](int j) -> int { return small ? rdlane_i(P.cls, j) : s.cls(j); };
+  auto mu_at = [&](int j) -> double { return small ? rdlane_d(P.mu, j) : s.mu(j); };
+  auto muc_at = [&](int j) -> double { return small ? rdlane_d(P.muc, j) : s.muc(j); };
+  auto rc_at = [&](int j) -> double { return small ? rdlane_d(P.rc, j) : s.rc(j); };
+  auto mn_at = [&](int j) -> double { return small ? rdlane_d(P.mn, j) : in.mn(j); };
+  auto mx_at = [&](int j) -> double { return small ? rdlane_d(P.mx, j) : in.mx(j); };
 
+  /* all-pairs speculation, mirror image of min_less_wave: pairs (start j, earlier piece k),
+   * tasks of one start ordered by decreasing k */
+  bool spec = false;
+  unsigned long long sp_ev = 0, sp_inside = 0;
+  double sp_mu = PSD_INF;
+  int my_base = 0;
+  if (small) {
+    unsigned long long m_start = ballot(lane < n && P.cls != CLS_STORE);
+    int total = 0;
+    for (unsigned long long m = m_start; m; m &= m - 1) total += ctz64(m);
+    if (total > 0 && total <= WAVE) {
+      spec = true;
+      int tj = -1, tk = 0, base = 0;
+      for (unsigned long long m = m_start; m; m &= m - 1) {
+        int j = ctz64(m), cnt = j;
+        if (lane == j) my_base = base;
+        if (lane >= base && lane < base + cnt) {
+          tj = j;
+          tk = j - 1 - (lane - base);
+        }
+        base += cnt;
+      }
+      bool inside = false, at_left = false;
+      if (tj >= 0) {
+        double level = (s.cls(tj) == CLS_CONST_MU) ? s.muc(tj) : s.rc(tj);
+        Coef c = load_coef(in, tk);
+        if (c.Log == 0) {
+          sp_mu = d_log((level - c.Constant) / c.Linear); /* fpl:563 */
+        } else {
+          PieceOpt o = {s.om(tk), s.mu(tk), s.muc(tk), s.oc2(tk)};
+          if (has_two_roots(c, o, level)) {
+            sp_mu = get_larger_root(c, o, in.mx(tk), s.rc(tk), level);
+          }
+        }
+        inside = in.mn(tk) < sp_mu && sp_mu < in.mx(tk);
+        if (!inside) at_left = s.lc(tk) <= level + NEWTON_EPSILON;
+      }
+      sp_ev = ballot(inside || at_left);
+      sp_inside = ballot(inside);
+    }
+  }
+  PSD_PROF_ADD(PROF_SERIAL); /* diagnostic builds: the speculation round */
   int n_out = 0; /* pieces written so far; piece p lives at out[cap-1-p] */
   int i0 = n - 1;
-  double prev_max_log_mean = in.mx(n - 1);
+  double prev_max_log_mean = mx_at(n - 1);
   for (;;) {
     /* ---- search mode, walking down from i0: first piece j <= i0 starting a constant ---- */
     int j = -1;
-    for (int base = i0 | (WAVE - 1); base >= 0; base -= WAVE) { /* base = top of a chunk */
-      int i = base - lane;
-      bool hit = i <= i0 && i >= 0 && s.cls(i) != CLS_STORE;
-      unsigned long long m = ballot(hit);
-      if (m) {
-        j = base - ctz64(m);
-        break;
+    if (small) {
+      unsigned long long m = ballot(lane <= i0 && P.cls != CLS_STORE);
+      if (m) j = msb64(m);
+    } else {
+      for (int base = i0 | (WAVE - 1); base >= 0; base -= WAVE) { /* base = top of a chunk */
+        int i = base - lane;
+        bool hit = i <= i0 && i >= 0 && s.cls(i) != CLS_STORE;
+        unsigned long long m = ballot(hit);
+        if (m) {
+          j = base - ctz64(m);
+          break;
+        }
       }
     }
     int cnt = i0 - j;
     if (n_out + cnt + 2 > cap) return -WERR_OVERFLOW;
-    for (int base = i0; base > j; base -= WAVE) {
-      int i = base - lane;
-      if (i > j) {
-        Coef c = load_coef(in, i);
-        double hi = (i == i0) ? prev_max_log_mean : in.mx(i);
-        store_piece(out, cap - 1 - (n_out + (i0 - i)), c, in.mn(i), hi, data_i_out, PSD_INF);
+    for (int base = i0; base > j; base -= (small ? n : WAVE)) {
+      int i = small ? lane : base - lane;
+      if (i > j && i <= i0) {
+        Coef c = small ? P.c : load_coef(in, i);
+        double mn_i = small ? P.mn : in.mn(i);
+        double mx_i = small ? P.mx : in.mx(i);
+        double hi = (i == i0) ? prev_max_log_mean : mx_i;
+        store_piece(out, cap - 1 - (n_out + (i0 - i)), c, mn_i, hi, data_i_out, PSD_INF);
       }
     }
     n_out += cnt;
-    if (cnt > 0) prev_max_log_mean = in.mn(j + 1);
+    if (cnt > 0) prev_max_log_mean = mn_at(j + 1);
     if (j < 0) break;
     double prev_min_cost, prev_best_log_mean;
-    if (s.cls(j) == CLS_CONST_MU) { /* fpl:524-537 */
-      double mu = s.mu(j);
+    if (cls_at(j) == CLS_CONST_MU) { /* fpl:524-537 */
+      double mu = mu_at(j);
       if (mu < prev_max_log_mean) {
         if (lane == 0)
           store_piece(out, cap - 1 - n_out, load_coef(in, j), mu, prev_max_log_mean, data_i_out,
@@ -470,39 +638,54 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, S s, int data_i_out)
       }
       prev_max_log_mean = mu;
       prev_best_log_mean = mu;
-      prev_min_cost = s.muc(j);
+      prev_min_cost = muc_at(j);
     } else { /* fpl:500-510 */
-      prev_min_cost = s.rc(j);
-      prev_best_log_mean = in.mx(j);
+      prev_min_cost = rc_at(j);
+      prev_best_log_mean = mx_at(j);
     }
     /* ---- constant mode: highest piece k < j where the constant ends (fpl:549-602) ---- */
     int k_ev = -1;
     bool ev_inside = false;
     double ev_mu = 0.0;
-    for (int base = j - 1; base >= 0; base -= WAVE) {
-      int k = base - lane;
-      bool inside = false, at_left = false;
-      double mu = PSD_INF;
-      if (k >= 0) {
-        Coef c = load_coef(in, k);
-        if (c.Log == 0) {
-          mu = d_log((prev_min_cost - c.Constant) / c.Linear); /* fpl:563 */
-        } else {
-          PieceOpt o = {s.om(k), s.mu(k), s.muc(k), s.oc2(k)};
-          if (has_two_roots(c, o, prev_min_cost)) {
-            mu = get_larger_root(c, o, in.mx(k), s.rc(k), prev_min_cost);
-          }
+    if (spec) {
+      if (j > 0) {
+        int base = rdlane_i(my_base, j);
+        unsigned long long range = (j >= 64 ? ~0ull : ((1ull << j) - 1ull)) << base;
+        unsigned long long ev = sp_ev & range;
+        if (ev) {
+          int src = ctz64(ev);
+          k_ev = j - 1 - (src - base);
+          ev_inside = ((sp_inside >> src) & 1ull) != 0;
+          ev_mu = rdlane_d(sp_mu, src);
         }
-        inside = in.mn(k) < mu && mu < in.mx(k);
-        if (!inside) at_left = s.lc(k) <= prev_min_cost + NEWTON_EPSILON;
       }
-      unsigned long long m_ev = ballot(inside || at_left);
-      if (m_ev) {
-        int src = ctz64(m_ev);
-        k_ev = base - src;
-        ev_inside = shfl_i(inside ? 1 : 0, src) != 0;
-        ev_mu = shfl_d(mu, src);
-        break;
+    } else {
+      for (int base = j - 1; base >= 0; base -= WAVE) {
+        int k = base - lane;
+        bool inside = false, at_left = false;
+        double mu = PSD_INF;
+        if (k >= 0) {
+          Coef c = load_coef(in, k);
+          if (c.Log == 0) {
+            mu = d_log((prev_min_cost - c.Constant) / c.Linear); /* fpl:563 */
+          } else {
+            PieceOpt o = {s.om(k), s.mu(k), s.muc(k), s.oc2(k)};
+            if (has_two_roots(c, o, prev_min_cost)) {
+              mu = get_larger_root(c, o, in.mx(k), s.rc(k), prev_min_cost);
+            }
+          }
+          inside = in.mn(k) < mu && mu < in.mx(k);
+          if (!inside) at_left = s.lc(k) <= prev_min_cost + NEWTON_EPSILON;
+        }
+        unsigned long long m_ev = ballot(inside || at_left);
+        unsigned long long m_in = ballot(inside);
+        if (m_ev) {
+          int src = ctz64(m_ev);
+          k_ev = base - src;
+          ev_inside = ((m_in >> src) & 1ull) != 0;
+          ev_mu = rdlane_d(mu, src);
+          break;
+        }
       }
     }
     Coef cc;
@@ -510,8 +693,9 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, S s, int data_i_out)
     cc.Log = 0.0;
     cc.Constant = prev_min_cost;
     if (k_ev < 0) { /* constant runs to the start (fpl:608-615) */
+      double mn_first = mn_at(0);
       if (lane == 0)
-        store_piece(out, cap - 1 - n_out, cc, in.mn(0), prev_max_log_mean, data_i_out,
+        store_piece(out, cap - 1 - n_out, cc, mn_first, prev_max_log_mean, data_i_out,
                     prev_best_log_mean);
       n_out++;
       break;
@@ -524,7 +708,7 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, S s, int data_i_out)
       prev_max_log_mean = ev_mu;
       i0 = k_ev;
     } else { /* fpl:591-601 */
-      double mnk = in.mn(k_ev);
+      double mnk = mn_at(k_ev);
       if (lane == 0)
         store_piece(out, cap - 1 - n_out, cc, mnk, prev_max_log_mean, data_i_out,
                     prev_best_log_mean);
@@ -539,7 +723,6 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, S s, int data_i_out)
   return n_out;
 }
 
-/* ------------------------------------------------------------------------------------- */
 /* Candidates emitted for one merged interval [a,b].  Every path of push_min_pieces emits
  * one of three shapes, with the source alternating between the two input pieces:
  *   n=1: [a,b]            n=2: [a,x1] [x1,b]            n=3: [a,x1] [x1,x2] [x2,b]
@@ -1174,7 +1357,7 @@ PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap, S s) {
     unsigned long long lb = lanes_below(lane);
     unsigned long long below = m_has & lb;
     const int my_last_id = (lsrc << 20) | (lsrc ? i2 : i1);
-    int pid = shfl_i(my_last_id, below ? msb64(below) : 0);
+    int pid = shfl_i(my_last_id, below ? msb64(below) : 0); /* per-lane source */
     if (!below) pid = last_id;
     const bool have_pred = pid >= 0;
     Coef pc = {0.0, 0.0, 0.0};
@@ -1231,7 +1414,7 @@ PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap, S s) {
     }
     wave_sync();
     n_out += heads_total;
-    if (m_has) last_id = shfl_i(my_last_id, msb64(m_has));
+    if (m_has) last_id = rdlane_i(my_last_id, msb64(m_has));
     PSD_PROF_ADD(PROF_COMPACT);
   }
   if (need_serial) {

@@ -20,6 +20,7 @@
 #define PSD_M inline
 #define PSD_NOINLINE static __attribute__((noinline))
 #define PSD_LDS static
+#define PSD_COLD_DEV static __attribute__((noinline, cold))
 #else
 #include <hip/hip_runtime.h>
 #define PSD_D __device__ __forceinline__
@@ -28,6 +29,7 @@
  * instruction cache (fully inlined it was ~200 KB) */
 #define PSD_NOINLINE __device__ __attribute__((noinline))
 #define PSD_LDS __shared__
+#define PSD_COLD_DEV __device__ __attribute__((noinline, cold))
 #endif
 
 #include "peakseg_detmath.h"
@@ -46,6 +48,9 @@ PSD_D int shfl_i(int v, int src) { return emu::shfl_i32(v, src); }
 PSD_D void wave_sync() { emu::wave_sync(); }
 PSD_D int uniform_i(int v) { return v; }
 PSD_D double uniform_d(double v) { return v; }
+/* value of lane `src`; src must be wave-uniform */
+PSD_D int rdlane_i(int v, int src) { return emu::shfl_i32(v, src); }
+PSD_D double rdlane_d(double v, int src) { return emu::shfl_f64(v, src); }
 #else
 PSD_D unsigned long long ballot(bool p) { return __ballot(p); }
 PSD_D double shfl_d(double v, int src) { return __shfl(v, src, 64); }
@@ -63,6 +68,18 @@ PSD_D double uniform_d(double v) {
   uint64_t u = psd_d2u(v);
   uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
   uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+  return psd_u2d(((uint64_t)hi << 32) | lo);
+}
+/* value of lane `src`; src must be wave-uniform: v_readlane_b32 takes a few cycles where a
+ * general shuffle (ds_bpermute) or an LDS broadcast read costs 60-100 in a dependent chain */
+PSD_D int rdlane_i(int v, int src) {
+  return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src));
+}
+PSD_D double rdlane_d(double v, int src) {
+  uint64_t u = psd_d2u(v);
+  int s = __builtin_amdgcn_readfirstlane(src);
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, s);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), s);
   return psd_u2d(((uint64_t)hi << 32) | lo);
 }
 #endif
