@@ -130,6 +130,17 @@ def main():
         assert start[-1] == -1 and (np.diff(start[:-1]) < 0).all()
 
     if rank == 0:
+        # HBM traffic of one forward launch from the PMC counters (collected separately with
+        # rocprofv3 --pmc, see profiles/r01/pmc_traffic.json); only valid for that workload
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if pmc["workload"]["bins"] == args.bins and \
+                    pmc["workload"]["penalties"] == args.penalties:
+                traffic = pmc["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         units = args.bins * args.penalties * world * args.steps
         total_pieces = sum(r.total_intervals for r in results)
         alg_bytes = 24.0 * args.bins * args.penalties + 20.0 * total_pieces
@@ -158,7 +169,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "fpop_forward_kernel",
                 "achieved": alg_bytes / fwd_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": alg_bytes / fwd_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "frac": alg_bytes / fwd_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": {"forward": float(np.mean(fwd)), "backtrack": float(np.mean(bwd))},
                 "dp_steps_per_s_per_problem": args.bins / fwd_s,
