@@ -27,7 +27,11 @@
 #endif
 
 #define NEWTON_EPSILON 1e-12 /* ref: fpl:9 */
+#ifdef ORACLE_NEWTON_STEPS /* tests only: force the step-cap fallback of the root finders */
+#define NEWTON_STEPS ORACLE_NEWTON_STEPS
+#else
 #define NEWTON_STEPS 100     /* ref: fpl:10 */
+#endif
 #define PREV_NOT_SET (-3)    /* ref: fpl:11 */
 #define ABS(x) ((x) < 0 ? -(x) : (x)) /* ref: fpl:13 */
 

@@ -19,7 +19,11 @@
 namespace psd {
 
 constexpr double NEWTON_EPSILON = 1e-12; /* fpl:9 */
+#ifdef PSD_NEWTON_STEPS /* tests only: force the step-cap fallback of the root finders */
+constexpr int NEWTON_STEPS = PSD_NEWTON_STEPS;
+#else
 constexpr int NEWTON_STEPS = 100;        /* fpl:10 */
+#endif
 constexpr int PREV_NOT_SET = -3;         /* fpl:11 */
 #define PSD_INF (__builtin_inf())
 

@@ -86,3 +86,58 @@ def gather_segment_tables(tables, dist=None, device=None):
                                  gathered[1][r][:n_seg].cpu().numpy(),
                                  gathered[2][r][:n_seg].cpu().numpy()))
     return out
+
+
+def predicted_cost(n_bins, penalty_rank, n_penalties):
+    """Relative cost of one problem for load balancing: proportional to the contig length,
+    rising about 2x from the smallest to the largest penalty of a log-spaced grid (measured:
+    28 k -> 47 k cycles per data point, profiles/r01/phase_shares_stamped_build.log)."""
+    return float(n_bins) * (1.0 + penalty_rank / max(1.0, n_penalties - 1.0))
+
+
+def solve_grid(contigs, penalties, dist=None, device=0, lib=None):
+    """Solve every (contig, penalty) problem of a grid across the ranks of `dist`
+    (BASELINE.json configs[3]: 24 contigs x 64 penalties over 8 GPUs).
+
+    contigs: list of (count, weight) int32 arrays, identical on every rank; penalties: list of
+    floats.  Problems are dealt to ranks longest-first; each rank uploads only the contigs it
+    needs, solves its shard in one problem set, and rank 0 receives everything through one
+    gather.  Returns on rank 0 a dict (contig_index, penalty_index) -> dict(seg_start,
+    seg_mean, summary) where summary = [n_segments, n_equality, max_intervals,
+    total_intervals, best_cost]; None on other ranks."""
+    from .grid import ProblemSet
+    world = 1 if dist is None else dist.get_world_size()
+    rank = 0 if dist is None else dist.get_rank()
+    order = sorted(range(len(penalties)), key=lambda i: penalties[i])
+    prank = {i: r for r, i in enumerate(order)}
+    problems = [(c, p) for c in range(len(contigs)) for p in range(len(penalties))]
+    costs = [predicted_cost(len(contigs[c][0]), prank[p], len(penalties)) for c, p in problems]
+    mine = shard_problems(costs, world)[rank]
+    used = sorted({problems[i][0] for i in mine})
+    local_of = {c: k for k, c in enumerate(used)}
+    tables = []
+    if mine:
+        pset = ProblemSet([contigs[c] for c in used],
+                          [(local_of[problems[i][0]], penalties[problems[i][1]]) for i in mine],
+                          device=device or 0, lib=lib)
+        pset.solve()
+        for k in range(len(mine)):
+            r = pset.result(k)
+            start, mean = pset.segments(k)
+            # one extra row carries the summary so that a single gather moves everything
+            summary = np.array([r.n_segments, r.n_equality_constraints, r.max_intervals,
+                                r.total_intervals, r.best_cost], dtype=np.float64)
+            tables.append((np.concatenate([start, np.full(5, -2, np.int32)]),
+                           np.concatenate([mean, summary])))
+        pset.close()
+    gathered = gather_segment_tables(tables, dist, device)
+    if rank != 0:
+        return None
+    shards = shard_problems(costs, world)
+    out = {}
+    for r in range(world):
+        for k, i in enumerate(shards[r]):
+            start, mean = gathered[r][k]
+            out[problems[i]] = {"seg_start": start[:-5], "seg_mean": mean[:-5],
+                                "summary": mean[-5:]}
+    return out

@@ -61,3 +61,38 @@ def test_emu_python_entry_points(psd, tmp_path):
 
 def test_emu_adversarial_spill(psd, oracle_det, tmp_path):
     gp.test_adversarial_increasing_counts_spill(psd, oracle_det, tmp_path, 1500)
+
+
+def test_emu_newton_step_cap_fallback(oracle_det, tmp_path):
+    """The root finders' 100-step fallback (bracket midpoint vs last iterate, fpl:109-120,
+    170-183) never triggers on real data, and the kernels keep the bracket bookkeeping out of
+    their hot loops, re-solving with it only when the cap is hit.  Build oracle and kernels
+    with the cap lowered to 5 steps so that most solves take that path, and compare."""
+    import numpy as np
+    from conftest import Oracle
+    import peaksegdisk_amd  # noqa: F401
+    from peaksegdisk_amd import _native, synthetic
+    from peaksegdisk_amd.grid import ProblemSet
+    subprocess.run(["make", "-s", "-C", EMU_DIR, "all"], check=True)
+    emu5 = _native.declare(ctypes.CDLL(os.path.join(EMU_DIR, "_build",
+                                                    "libpeaksegdisk_emu_steps5.so")))
+    oracle5 = Oracle("det_steps5")
+    cs, ce, cnt = synthetic.poisson_coverage(1200, seed=21)
+    pens = ["0.5", "40", "3000"]
+    pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, float(p)) for p in pens],
+                      lib=emu5)
+    pset.solve()
+    bg = str(tmp_path / "coverage.bedGraph")
+    synthetic.write_bedgraph(bg, cs, ce, cnt)
+    differs_from_100 = False
+    for i, pen in enumerate(pens):
+        db5 = str(tmp_path / ("o5_%d.db" % i))
+        assert oracle5.solve(bg, pen, db5) == 0
+        dbg = str(tmp_path / ("g5_%d.db" % i))
+        pset.export_db(i, ce, dbg)
+        assert open(dbg, "rb").read() == open(db5, "rb").read(), pen
+        db100 = str(tmp_path / ("o100_%d.db" % i))
+        assert oracle_det.solve(bg, pen, db100) == 0
+        differs_from_100 = differs_from_100 or open(db100, "rb").read() != open(db5, "rb").read()
+    assert differs_from_100, "cap of 5 steps did not change anything: fallback not exercised"
+    pset.close()

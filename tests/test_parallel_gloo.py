@@ -87,3 +87,58 @@ def test_pack_unpack_roundtrip_with_empty():
     t = _tables_for_rank(1)
     back = unpack_tables(*pack_tables(t))
     assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(t, back))
+
+
+def _grid_worker(rank, world, port, out_q):
+    """2 gloo ranks solve a 3-contig x 4-penalty grid with the emulated kernels; rank 0 checks
+    every problem against a single-process solve of the same grid."""
+    import ctypes
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from peaksegdisk_amd import _native, synthetic
+    from peaksegdisk_amd.parallel import solve_grid
+    emu = _native.declare(ctypes.CDLL(os.path.join(ROOT, "tests", "emu", "_build",
+                                                   "libpeaksegdisk_emu.so")))
+    contigs = []
+    for k, n in enumerate((300, 500, 200)):
+        cs, ce, cnt = synthetic.poisson_coverage(n, seed=50 + k)
+        contigs.append((cnt, (ce - cs).astype(np.int32)))
+    pens = [0.3, 7.0, 150.0, 4000.0]
+    got = solve_grid(contigs, pens, dist, None, lib=emu)
+    ok = True
+    if rank == 0:
+        ref = solve_grid(contigs, pens, None, 0, lib=emu)
+        ok = set(got) == set(ref) and len(got) == 12
+        for key in ref:
+            ok = ok and np.array_equal(got[key]["seg_start"], ref[key]["seg_start"])
+            ok = ok and np.array_equal(got[key]["seg_mean"], ref[key]["seg_mean"])
+            ok = ok and np.array_equal(got[key]["summary"], ref[key]["summary"])
+            ok = ok and got[key]["summary"][0] == len(got[key]["seg_start"])
+    else:
+        ok = got is None
+    out_q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_solve_grid_sharded_gloo_world2():
+    import subprocess
+    import torch.multiprocessing as mp
+    import __graft_entry__ as entry
+    entry.build_hip()
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")], check=True)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grid_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    results = [q.get(timeout=10) for _ in procs]
+    assert results == [True, True]
