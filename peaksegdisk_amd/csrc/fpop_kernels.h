@@ -184,6 +184,58 @@ PSD_D bool arena_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &f, i
   return true;
 }
 
+/* Last phase of a step, fused: f <- (f * W_{t-1} + (w, -z w, 0)) * (1/W_t)  (drv:316-321 /
+ * 365-370: multiply, add, multiply, no contraction) and the function's backtrack record
+ * {max_log_mean, data_i, prev_log_mean} appended to the arena, each piece touched once.
+ * Returns false when the arena is full. */
+template <class L>
+PSD_D bool scale_add_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &f, int n,
+                                unsigned long long fn_index, bool store, double cum_weight_prev,
+                                double add_linear, double add_log, double inv_cum_weight) {
+  const int lane = lane_id();
+  bool ok = true;
+  if (store && n > cur.room - cur.used) {
+    int chunks = (n + ARENA_CHUNK - 1) >> ARENA_CHUNK_LOG2;
+    unsigned long long first = 0;
+    if (lane == 0) first = atomicAdd(a.ar_next_chunk, (unsigned long long)chunks);
+    first = psd_d2u(rdlane_d(psd_u2d(first), 0));
+    cur.base = first << ARENA_CHUNK_LOG2;
+    cur.used = 0;
+    cur.room = chunks << ARENA_CHUNK_LOG2;
+    if (cur.base + (unsigned long long)cur.room > a.ar_cap) {
+      ok = false;
+      store = false;
+    }
+  }
+  const unsigned long long off = cur.base + (unsigned long long)cur.used;
+  for (int base = 0; base < n; base += WAVE) {
+    int i = base + lane;
+    if (i < n) {
+      double li = f.Lin(i) * cum_weight_prev;
+      double lo = f.Log(i) * cum_weight_prev;
+      double co = f.Con(i) * cum_weight_prev;
+      double mx = f.mx(i), prv = f.prv(i);
+      int di = f.di(i);
+      li = li + add_linear;
+      lo = lo + add_log;
+      co = co + 0.0;
+      f.Lin(i) = li * inv_cum_weight;
+      f.Log(i) = lo * inv_cum_weight;
+      f.Con(i) = co * inv_cum_weight;
+      if (store) {
+        a.ar_mx[off + i] = mx;
+        a.ar_prv[off + i] = prv;
+        a.ar_di[off + i] = di;
+      }
+    }
+  }
+  if (store) {
+    if (lane == 0) a.fn_ref[fn_index] = (off << FN_COUNT_BITS) | (unsigned long long)n;
+    cur.used += n;
+  }
+  return ok;
+}
+
 /* Minimize (fpl:689-712): first strict minimum over pieces of the clamped optimum. */
 template <class L>
 PSD_D void minimize_wave(const L &f, int n, double *best_cost, double *best_log_mean,
@@ -245,7 +297,8 @@ PSD_D void copy_list_across(const LS &src, int n, const LD &dst) {
  * then multiply, add the data point, multiply (drv:316-321,365-370).
  * Returns the new piece count or -(WERR_* bits). */
 template <class L, class S>
-PSD_D int chain_step(int chain, int t, const L &other_prev, int n_other, const L &own_prev,
+PSD_D int chain_step(const DeviceArgs &a, ArenaCursor &cur, unsigned long long fn_index,
+                     int chain, int t, const L &other_prev, int n_other, const L &own_prev,
                      int n_own, const L &own_new, const L &mlist, const S &sc, int cap,
                      double pen_term, double cum_weight_prev, double w, int coverage,
                      double cum_weight) {
@@ -272,10 +325,11 @@ PSD_D int chain_step(int chain, int t, const L &other_prev, int n_other, const L
   if (n_new < 0) return n_new;
   PSD_PROF_T0();
   wave_sync();
-  scale_add_wave(own_new, n_new, cum_weight_prev, w, (double)(-coverage) * w, 1 / cum_weight);
+  bool ok = scale_add_store_wave(a, cur, own_new, n_new, fn_index, true, cum_weight_prev, w,
+                                 (double)(-coverage) * w, 1 / cum_weight);
   wave_sync();
   PSD_PROF_ADD(PROF_SCALE);
-  return n_new;
+  return ok ? n_new : -WERR_ARENA;
 }
 
 /* list ids: 2*chain + buffer for the two cost functions (chain 0 = up, 1 = down), 4 + chain
@@ -364,12 +418,14 @@ __global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
           n_new = 1;
         }
       } else if (!in_hbm) {
-        n_new = chain_step(chain, t, lds_list(id_other_prev), n_other, lds_list(id_own_prev),
+        n_new = chain_step(a, cur, fn0 + (unsigned long long)t, chain, t,
+                           lds_list(id_other_prev), n_other, lds_list(id_own_prev),
                            n_own, lds_list(id_own_new), mlist, lsc, LDS_CAP,
                            penalty / cum_weight_prev_i, cum_weight_prev_i, w, coverage,
                            cum_weight_new);
       } else {
-        n_new = chain_step(chain, t, global_list(a, p, id_other_prev), n_other,
+        n_new = chain_step(a, cur, fn0 + (unsigned long long)t, chain, t,
+                           global_list(a, p, id_other_prev), n_other,
                            global_list(a, p, id_own_prev), n_own, global_list(a, p, id_own_new),
                            global_list(a, p, 4 + chain), global_scratch(a, p, chain),
                            a.spill_cap, penalty / cum_weight_prev_i, cum_weight_prev_i, w,
@@ -382,15 +438,13 @@ __global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
       if (n_new < 0) {
         if (lane == 0) {
           g_sm.abort_err[slot] = -n_new;
-          g_sm.abort_status[slot] =
-              ((-n_new) & WERR_OVERFLOW) ? PST_LDS_OVERFLOW : PST_REF_THROW;
+          g_sm.abort_status[slot] = ((-n_new) & WERR_ARENA)      ? PST_ARENA_FULL
+                                    : ((-n_new) & WERR_OVERFLOW) ? PST_LDS_OVERFLOW
+                                                                 : PST_REF_THROW;
         }
-      } else if (chain == 1 || t > 0) {
-        bool ok = in_hbm ? arena_store_wave(a, cur, global_list(a, p, id_own_new), n_new,
-                                            fn0 + (unsigned long long)t)
-                         : arena_store_wave(a, cur, lds_list(id_own_new), n_new,
-                                            fn0 + (unsigned long long)t);
-        if (!ok && lane == 0) g_sm.abort_status[slot] = PST_ARENA_FULL;
+      } else if (t == 0 && chain == 1) { /* down_0 is stored unscaled (drv:266-270,391) */
+        if (!arena_store_wave(a, cur, lds_list(id_own_new), n_new, fn0) && lane == 0)
+          g_sm.abort_status[slot] = PST_ARENA_FULL;
       }
       PSD_PROF_ADD(PROF_ARENA);
       __syncthreads();

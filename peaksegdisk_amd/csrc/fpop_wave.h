@@ -201,6 +201,7 @@ enum {
   WERR_REF_THROW = 2,     /* fpl:380 decreasing degenerate linear piece */
   WERR_SENTINEL = 4,      /* push_min_pieces neighbour outside the list */
   WERR_ZERO_INTERVAL = 8, /* fpl:933 zero-size merged interval */
+  WERR_ARENA = 16,        /* the in-HBM store is full */
 };
 
 /* A lane's own copy of piece `lane` and of what the first pass computed for it (functions of
@@ -1147,54 +1148,49 @@ PSD_D void env_classify_lanes(bool valid, const Coef &c1, const Coef &c2, double
   }
 }
 
-/* Loads merged interval (i1,i2): the two pieces, the interval, and the neighbour-equality
- * flags push_min_pieces derives from the pieces next to them (fpl:876-932). */
+/* Loads merged interval (i1,i2): the two pieces and the interval [a,b] (fpl:876-932 without
+ * the neighbour tests, see env_neighbour_flags). */
 template <class L>
 PSD_D void env_load_interval(const L &f1, int n1, const L &f2, int n2, int i1, int i2, Coef &c1,
-                             Coef &c2, double &a, double &b, bool &same_at_left,
-                             bool &same_at_right, int &err) {
+                             Coef &c2, double &a, double &b, int &err) {
   c1 = load_coef(f1, i1);
   c2 = load_coef(f2, i2);
   double mn1 = f1.mn(i1), mx1 = f1.mx(i1), mn2 = f2.mn(i2), mx2 = f2.mx(i2);
-  bool sentinel = false;
-  if (mn1 < mn2) {
-    if (i2 == 0) sentinel = true;
-    same_at_left = !sentinel && same_funs(load_coef(f2, i2 - 1), c1);
-    a = mn2;
-  } else {
-    a = mn1;
-    if (mn2 < mn1) {
-      if (i1 == 0) sentinel = true;
-      same_at_left = !sentinel && same_funs(load_coef(f1, i1 - 1), c2);
-    } else {
-      if (i1 == 0 && i2 == 0) {
-        same_at_left = false;
-      } else {
-        if (i1 == 0 || i2 == 0) sentinel = true;
-        same_at_left = !sentinel && same_funs(load_coef(f1, i1 - 1), load_coef(f2, i2 - 1));
-      }
-    }
-  }
-  if (mx1 < mx2) {
-    if (i1 + 1 >= n1) sentinel = true;
-    same_at_right = !sentinel && same_funs(load_coef(f1, i1 + 1), c2);
-    b = mx1;
-  } else {
-    b = mx2;
-    if (mx2 < mx1) {
-      if (i2 + 1 >= n2) sentinel = true;
-      same_at_right = !sentinel && same_funs(c1, load_coef(f2, i2 + 1));
-    } else {
-      if (i1 + 1 == n1 && i2 + 1 == n2) {
-        same_at_right = false;
-      } else {
-        if (i1 + 1 >= n1 || i2 + 1 >= n2) sentinel = true;
-        same_at_right = !sentinel && same_funs(load_coef(f1, i1 + 1), load_coef(f2, i2 + 1));
-      }
-    }
-  }
+  /* the piece that started earlier / ends later must have a neighbour on that side; the
+   * reference would read a std::list sentinel otherwise */
+  bool sentinel = (mn1 < mn2 && i2 == 0) || (mn2 < mn1 && i1 == 0) ||
+                  (mn1 == mn2 && (i1 == 0) != (i2 == 0)) || (mx1 < mx2 && i1 + 1 >= n1) ||
+                  (mx2 < mx1 && i2 + 1 >= n2) ||
+                  (mx1 == mx2 && (i1 + 1 == n1) != (i2 + 1 == n2));
+  a = mn1 < mn2 ? mn2 : mn1;
+  b = mx1 < mx2 ? mx1 : mx2;
   if (sentinel) err |= WERR_SENTINEL;
   if (a == b) err |= WERR_ZERO_INTERVAL; /* fpl:933-944 */
+}
+
+/* same_at_left / same_at_right of push_min_pieces (fpl:876-932) compare the pieces next to
+ * (it1, it2) in the two input lists.  Those neighbours are exactly the pair of pieces of the
+ * previous / next merged interval: if it1 starts before it2 the previous interval is
+ * (it1, prev2), if it2 starts first it is (prev1, it2), if both start together (prev1, prev2)
+ * -- and the test made is sameFuns of that pair in each case; symmetrically on the right.
+ * So same_at_left(k) = sameFuns of interval k-1, same_at_right(k) = sameFuns of interval k+1
+ * (false at the two ends of the function, fpl:894-896,919-922). */
+template <class L, class S>
+PSD_D void env_neighbour_flags(const L &f1, const L &f2, const S &s, int k, int K, bool valid,
+                               bool triv, bool &same_at_left, bool &same_at_right) {
+  const int lane = lane_id();
+  unsigned long long m_triv = ballot(valid && triv);
+  same_at_left = lane > 0 && ((m_triv >> (lane - 1)) & 1ull) != 0;
+  same_at_right = lane < WAVE - 1 && ((m_triv >> (lane + 1)) & 1ull) != 0;
+  /* chunk edges (functions with more than 64 merged intervals): look the neighbour up */
+  if (valid && lane == 0 && k > 0) {
+    int e = s.iv(k - 1);
+    same_at_left = same_funs(load_coef(f1, e >> 16), load_coef(f2, e & 0xffff));
+  }
+  if (valid && lane == WAVE - 1 && k + 1 < K) {
+    int e = s.iv(k + 1);
+    same_at_right = same_funs(load_coef(f1, e >> 16), load_coef(f2, e & 0xffff));
+  }
 }
 
 /* push_piece's "same as last" test (fpl:1270-1273) */
@@ -1258,7 +1254,40 @@ PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap, S s) {
   PSD_PROF_T0();
   /* ---- merged-interval table: interval k ends at the k-th distinct max_log_mean ---- */
   int K;
-  {
+  if (n1 <= 32 && n2 <= 32) {
+    /* both lists in one pass: lanes 0-31 rank the ends of f1 in f2, lanes 32-63 those of f2
+     * in f1 (the usual case: one ballot, one pass of broadcast reads) */
+    const int side = lane >> 5, idx = lane & 31;
+    const int n_own = side ? n2 : n1, n_oth = side ? n1 : n2;
+    const L &own = side ? f2 : f1;
+    const L &oth = side ? f1 : f2;
+    const bool valid = idx < n_own;
+    double x = 0.0;
+    int p = 0;
+    bool dup = false;
+    if (valid) x = own.mx(idx);
+    const int n_max = n1 > n2 ? n1 : n2;
+    double at_p = 0.0;
+    for (int j = 0; j < n_max; j++) {
+      if (valid && j < n_oth) {
+        double v = oth.mx(j);
+        if (v < x) {
+          p++;
+        } else if (v == x) {
+          at_p = v;
+          dup = true;
+        }
+      }
+    }
+    (void)at_p;
+    unsigned long long md = ballot(dup);
+    const unsigned long long half = side ? (md >> 32) : (md & 0xffffffffull);
+    if (valid && !(side && dup)) {
+      int k = idx + p - popc64(half & lanes_below(idx));
+      if (k < iv_cap) s.iv(k) = side ? ((p << 16) | idx) : ((idx << 16) | p);
+    }
+    K = n1 + n2 - popc64(md & 0xffffffffull);
+  } else {
     int dup_before = 0; /* ends of f1 that are also ends of f2, among earlier chunks */
     for (int base = 0; base < n1; base += WAVE) {
       int i = base + lane;
@@ -1326,12 +1355,13 @@ PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap, S s) {
       int e = s.iv(k);
       i1 = e >> 16;
       i2 = e & 0xffff;
-      env_load_interval(f1, n1, f2, n2, i1, i2, c1, c2, ia, ib, sl, sr, err);
+      env_load_interval(f1, n1, f2, n2, i1, i2, c1, c2, ia, ib, err);
       prv1 = f1.prv(i1);
       di1 = f1.di(i1);
       prv2 = f2.prv(i2);
       di2 = f2.di(i2);
     }
+    env_neighbour_flags(f1, f2, s, k, K, valid, valid && same_funs(c1, c2), sl, sr);
     PSD_PROF_ADD(PROF_C_LOAD);
     env_classify_lanes(valid && err == 0, c1, c2, ia, ib, sl, sr, cd);
     PSD_PROF_ADD(PROF_CLASSIFY);
