@@ -96,3 +96,32 @@ def test_emu_newton_step_cap_fallback(oracle_det, tmp_path):
         differs_from_100 = differs_from_100 or open(db100, "rb").read() != open(db5, "rb").read()
     assert differs_from_100, "cap of 5 steps did not change anything: fallback not exercised"
     pset.close()
+
+
+def test_emu_grid_properties_small(psd):
+    """The property checks of the full-size GPU test on a small grid (structure of the test
+    itself; the arithmetic is the same)."""
+    import numpy as np
+    from peaksegdisk_amd import ProblemSet, synthetic
+    cs, ce, cnt = synthetic.poisson_coverage(3000, seed=1)
+    w = (ce - cs).astype(np.int32)
+    pens = synthetic.penalty_grid(6)
+    pset = ProblemSet([(cnt, w)], [(0, float(p)) for p in pens])
+    pset.solve()
+    cw = np.concatenate([[0.0], np.cumsum(w.astype(np.float64))])
+    cz = np.concatenate([[0.0], np.cumsum(w.astype(np.float64) * cnt)])
+    peaks = []
+    for i, pen in enumerate(pens):
+        r = pset.result(i)
+        start, mean = pset.segments(i)
+        lo = start[::-1] + 1
+        hi = np.concatenate([lo[1:], [3000]])
+        m = mean[::-1]
+        assert (m[1::2] >= m[0:-1:2]).all() and (m[1::2] >= m[2::2]).all()
+        seg_w, seg_z = cw[hi] - cw[lo], cz[hi] - cz[lo]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            loss = np.where(seg_z > 0, seg_w * m - seg_z * np.log(m), seg_w * m).sum()
+        assert r.best_cost * cw[-1] - float(pen) * r.n_peaks == pytest.approx(loss, rel=1e-6)
+        peaks.append(r.n_peaks)
+    assert all(a >= b for a, b in zip(peaks, peaks[1:]))
+    pset.close()

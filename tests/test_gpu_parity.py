@@ -242,3 +242,74 @@ def test_adversarial_increasing_counts_spill(psd, oracle_det, tmp_path, n_bins):
     assert spilled > 0, "test did not reach the spill path"
     assert pset.result(0).max_intervals > 128
     pset.close()
+
+
+@GPU
+def test_full_size_grid_properties(psd, oracle_det, tmp_path):
+    """BASELINE.json configs[1] at full size (1e6 bins x 64 penalties): properties that do not
+    need the oracle at that size, plus two penalties checked against the oracle outright.
+      * every problem solves; segment tables are well formed (odd row count, strictly
+        decreasing starts, last row = first_chromStart);
+      * up/down constraint: means rise into every peak and fall out of it;
+      * the reported total loss equals the Poisson loss recomputed from the segmentation
+        (sum over segments of w*m - z*log m) to 1e-6 relative -- a checksum of the whole
+        forward pass and backtrack;
+      * the number of peaks does not increase with the penalty;
+      * solving again gives bit-identical results (determinism)."""
+    from peaksegdisk_amd import ProblemSet, synthetic
+    n_bins = 1000000
+    cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=1)
+    w = (ce - cs).astype(np.int32)
+    pens = synthetic.penalty_grid(64)
+    pset = ProblemSet([(cnt, w)], [(0, float(p)) for p in pens])
+    pset.solve()
+    cw = np.concatenate([[0.0], np.cumsum(w.astype(np.float64))])
+    cz = np.concatenate([[0.0], np.cumsum(w.astype(np.float64) * cnt)])
+    peaks = []
+    first = []
+    for i, pen in enumerate(pens):
+        r = pset.result(i)
+        assert r.status == 0, (pen, r.kernel_status)
+        start, mean = pset.segments(i)
+        first.append((start.copy(), mean.copy(), r.best_cost))
+        assert len(start) == r.n_segments and len(start) % 2 == 1
+        assert start[-1] == -1 and (np.diff(start[:-1]) < 0).all()
+        # genomic order: segment g covers data (lo[g], hi[g]]
+        lo = start[::-1] + 1
+        hi = np.concatenate([lo[1:], [n_bins]])
+        m = mean[::-1]
+        up = m[1::2] >= m[0:-1:2]      # background -> peak
+        down = m[1::2] >= m[2::2]      # peak -> background
+        assert up.all() and down.all(), pen
+        seg_w = cw[hi] - cw[lo]
+        seg_z = cz[hi] - cz[lo]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            loss = np.where(seg_z > 0, seg_w * m - seg_z * np.log(m), seg_w * m).sum()
+        total = r.best_cost * cw[-1] - float(pen) * r.n_peaks
+        assert total == pytest.approx(loss, rel=1e-6, abs=1e-6), pen
+        peaks.append(r.n_peaks)
+    assert all(a >= b for a, b in zip(peaks, peaks[1:])), peaks
+    assert peaks[0] > 1000 * peaks[-1] > 0
+    # determinism
+    pset.solve()
+    for i in (0, 31, 63):
+        start, mean = pset.segments(i)
+        assert np.array_equal(start, first[i][0])
+        assert np.array_equal(mean.view(np.uint64), first[i][1].view(np.uint64))
+        assert pset.result(i).best_cost == first[i][2]
+    # two penalties against the oracle at full size
+    bg = str(tmp_path / "coverage.bedGraph")
+    synthetic.write_bedgraph(bg, cs, ce, cnt)
+    for i in (20, 50):
+        assert oracle_det.solve(bg, pens[i]) == 0
+        segs = read_segments("%s_penalty=%s_segments.bed" % (bg, pens[i]))
+        start, mean = pset.segments(i)
+        assert [s[1] for s in segs] == [int(cs[0]) if k < 0 else int(ce[k]) for k in start]
+        assert [s[4] for s in segs] == ["%g" % v for v in mean]
+        loss = read_loss("%s_penalty=%s_loss.tsv" % (bg, pens[i])).split("\t")
+        r = pset.result(i)
+        assert loss[5] == "%.20g" % r.best_cost and float(loss[9]) == r.max_intervals
+        assert int(loss[7]) == r.n_equality_constraints
+        assert float(loss[8]) == r.total_intervals / (2.0 * n_bins)
+        os.unlink("%s_penalty=%s.db" % (bg, pens[i]))
+    pset.close()
