@@ -75,14 +75,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    # RCCL ("nccl") on GPUs; tests/test_bench_multirank.py rehearses the N>1 plumbing on CPU
+    # with PSD_BENCH_BACKEND=gloo
+    backend = os.environ.get("PSD_BENCH_BACKEND", "nccl")
+    on_gpu = backend == "nccl"
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = local_rank if world > 1 else 0
+        if on_gpu:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    device = local_rank if (world > 1 and on_gpu) else 0
 
     import __graft_entry__ as entry
-    entry.build_hip()
+    if rank == 0 or not os.path.exists(entry.LIB):
+        entry.build_hip()
+    if dist is not None:
+        dist.barrier()
     from peaksegdisk_amd import ProblemSet, synthetic
     from peaksegdisk_amd.parallel import gather_segment_tables
 
@@ -94,7 +104,8 @@ def main():
     pset = ProblemSet([(cnt, weight)], problems, device=device)
 
     def sync():
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
@@ -117,7 +128,7 @@ def main():
     sync()
     elapsed = time.time() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -125,3 +125,7 @@ def test_emu_grid_properties_small(psd):
         peaks.append(r.n_peaks)
     assert all(a >= b for a, b in zip(peaks, peaks[1:]))
     pset.close()
+
+
+def test_emu_fuzz_tiny_problems(psd, oracle_det, tmp_path):
+    gp.test_fuzz_tiny_problems(psd, oracle_det, tmp_path, 150, 6)

@@ -313,3 +313,59 @@ def test_full_size_grid_properties(psd, oracle_det, tmp_path):
         assert float(loss[8]) == r.total_intervals / (2.0 * n_bins)
         os.unlink("%s_penalty=%s.db" % (bg, pens[i]))
     pset.close()
+
+
+@GPU
+@pytest.mark.parametrize("n_cases,seed", [(300, 5)])
+def test_fuzz_tiny_problems(psd, oracle_det, tmp_path, n_cases, seed):
+    """Many tiny random problems in one problem set (ragged lengths 1..40, zeros, repeated
+    counts, increasing/decreasing runs, wide count ranges, penalties from 0 to 1e6): the rare
+    branches of the piece algebra (degenerate linear pieces, equal-at-left/right, crossings at
+    interval ends) against the oracle, problem by problem."""
+    from peaksegdisk_amd import ProblemSet
+    rng = np.random.default_rng(seed)
+    contigs, problems, texts, pens = [], [], [], []
+    for c in range(n_cases):
+        n = int(rng.integers(2, 41))
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            cnt = rng.integers(0, 3, n)
+        elif kind == 1:
+            cnt = rng.integers(0, 50, n)
+        elif kind == 2:
+            cnt = np.sort(rng.integers(0, 30, n))
+        elif kind == 3:
+            cnt = np.sort(rng.integers(0, 30, n))[::-1]
+        else:
+            cnt = np.repeat(rng.integers(0, 8, (n + 3) // 4), 4)[:n]
+        if (cnt == cnt[0]).all():
+            cnt[-1] += 1  # constant data takes the closed-form branch on the host, not the DP
+        wid = rng.integers(1, 30, n)
+        end = np.cumsum(wid)
+        start = end - wid
+        pen = "0" if rng.random() < 0.15 else "%.15g" % (10.0 ** rng.uniform(-2, 6))
+        contigs.append((cnt.astype(np.int32), wid.astype(np.int32)))
+        problems.append((c, float(pen)))
+        pens.append(pen)
+        texts.append(("".join("chrF\t%d\t%d\t%d\n" % t for t in zip(start, end, cnt)), end))
+    pset = ProblemSet(contigs, problems)
+    pset.solve()
+    for c in range(n_cases):
+        d = tmp_path / ("f%d" % c)
+        d.mkdir()
+        bg = str(d / "coverage.bedGraph")
+        open(bg, "w").write(texts[c][0])
+        assert oracle_det.solve(bg, pens[c]) == 0
+        r = pset.result(c)
+        assert r.status == 0, (c, r.kernel_status)
+        seg_start, seg_mean = pset.segments(c)
+        segs = read_segments("%s_penalty=%s_segments.bed" % (bg, pens[c]))
+        end = texts[c][1]
+        assert [s[1] for s in segs] == [0 if k < 0 else int(end[k]) for k in seg_start], c
+        assert [s[4] for s in segs] == ["%g" % v for v in seg_mean], c
+        loss = read_loss("%s_penalty=%s_loss.tsv" % (bg, pens[c])).split("\t")
+        assert loss[5] == "%.20g" % r.best_cost, c
+        assert int(loss[7]) == r.n_equality_constraints
+        assert float(loss[9]) == r.max_intervals
+        assert float(loss[8]) == r.total_intervals / (2.0 * len(end))
+    pset.close()
