@@ -47,7 +47,11 @@ PSD_D double argmin(const Coef &c) { return d_log(argmin_mean(c)); }
 
 /* fpl:206-222 */
 PSD_D double get_cost(const Coef &c, double log_mean) {
-  double linear_term = (log_mean == -PSD_INF) ? 0.0 : c.Linear * d_exp(log_mean);
+  /* the reference skips exp() at -Inf and uses 0; here exp is evaluated at a harmless argument
+   * and the product is replaced by 0 with a select (no exec-mask branch around the hot path) */
+  const bool at_zero_mean = log_mean == -PSD_INF;
+  double e = d_exp(at_zero_mean ? 0.0 : log_mean);
+  double linear_term = at_zero_mean ? 0.0 : c.Linear * e;
   double log_term = (c.Log == 0) ? 0.0 : c.Log * log_mean;
   return linear_term + log_term + c.Constant;
 }
@@ -225,7 +229,9 @@ PSD_D double get_smaller_root(const Coef &c, const PieceOpt &o, double min_log_m
   int step = 0;
   do {
     /* getCost and getDeriv (fpl:206-234) evaluate the same Linear*exp(x): once here */
-    double linear_term = (candidate_root == -PSD_INF) ? 0.0 : c.Linear * d_exp(candidate_root);
+    const bool at_zero_mean = candidate_root == -PSD_INF;
+    double e = d_exp(at_zero_mean ? 0.0 : candidate_root);
+    double linear_term = at_zero_mean ? 0.0 : c.Linear * e;
     double log_term = (c.Log == 0) ? 0.0 : c.Log * candidate_root;
     candidate_cost = (linear_term + log_term + c.Constant) - equals;
     if (NEWTON_STEPS <= ++step)

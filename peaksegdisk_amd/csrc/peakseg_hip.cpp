@@ -89,7 +89,8 @@ int read_bedGraph(const char *path, Coverage &cv) {
   int status = 0;
   while (getline(&line, &cap, f) != -1) {
     line_i++;
-    items = sscanf(line, "%s %d %d %d%s\n", chrom, &chromStart, &chromEnd, &coverage, extra);
+    /* the reference reads "%s" into char[100] buffers (drv:166-167,175-178); bounded here */
+    items = sscanf(line, "%99s %d %d %d%99s\n", chrom, &chromStart, &chromEnd, &coverage, extra);
     if (items < 4) {
       emit_text("problem: %d items on line %d\n", items, line_i);
       status = ERROR_NOT_ENOUGH_COLUMNS;
@@ -274,7 +275,7 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
     int n = contig_n_bins[c];
     if (n <= 0 || n >= (1 << 30)) {
       set_error("contig %d has %d bins", c, n);
-      delete s;
+      peakseg_hip_problem_set_destroy(s);
       return ERROR_DEVICE_SOLVER;
     }
     s->contig_n.push_back(n);
@@ -297,7 +298,7 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
     int c = problem_contig[p];
     if (c < 0 || c >= n_contigs) {
       set_error("problem %d names contig %d", p, c);
-      delete s;
+      peakseg_hip_problem_set_destroy(s);
       return ERROR_DEVICE_SOLVER;
     }
     s->prob_contig.push_back(c);

@@ -134,3 +134,24 @@ def test_r_paste_formatting():
     assert paste(1952.6687694641800423) == "1952.66876946418"
     assert paste(866939314852865280.0) == "866939314852865280"
     assert paste("10.50") == "10.50"
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/peaksegdisk_hip.h must be consumable from C (the R glue and cgo-style bindings):
+    no C++ or torch types in the signatures."""
+    import subprocess
+    src = tmp_path / "use.c"
+    src.write_text('#include "peaksegdisk_hip.h"\n'
+                   'int use(char *a, char *b, char *c) { psd_result r; (void)r;\n'
+                   '  return PeakSegFPOP_disk(a, b, c); }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only",
+                    "-I" + os.path.join(ROOT, "include"), str(src)], check=True)
+
+
+def test_detmath_header_is_plain_c(tmp_path):
+    import subprocess
+    src = tmp_path / "m.c"
+    src.write_text('#include "peakseg_detmath.h"\n'
+                   'double f(double x) { return psd_exp(x) + psd_log(x); }\n')
+    subprocess.run(["gcc", "-std=gnu99", "-Wall", "-Werror", "-fsyntax-only", "-ffp-contract=off",
+                    "-I" + os.path.join(ROOT, "include"), str(src)], check=True)
