@@ -195,6 +195,13 @@ PSD_D void store_piece(const L &f, int i, const Coef &c, double mn, double mx, i
 
 enum { CLS_STORE = 0, CLS_CONST_EDGE = 1, CLS_CONST_MU = 2 };
 
+/* how many pieces after (before) a constant's start the all-pairs speculation of min_less
+ * (min_more) covers; the rest is scanned only if no crossing was found among them */
+#ifndef PSD_SPEC_WINDOW
+#define PSD_SPEC_WINDOW 5
+#endif
+constexpr int SPEC_WINDOW = PSD_SPEC_WINDOW;
+
 /* error bits (the reference would throw / loop / read a sentinel) */
 enum {
   WERR_OVERFLOW = 1,      /* output does not fit `cap` */
@@ -327,12 +334,16 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
   if (small) {
     unsigned long long m_start = ballot(lane < n && P.cls != CLS_STORE);
     int total = 0;
-    for (unsigned long long m = m_start; m; m &= m - 1) total += n - 1 - ctz64(m);
+    for (unsigned long long m = m_start; m; m &= m - 1) {
+      int c = n - 1 - ctz64(m);
+      total += c < SPEC_WINDOW ? c : SPEC_WINDOW;
+    }
     if (total > 0 && total <= WAVE) {
       spec = true;
       int tj = -1, tk = 0, base = 0;
       for (unsigned long long m = m_start; m; m &= m - 1) {
         int j = ctz64(m), cnt = n - 1 - j;
+        if (cnt > SPEC_WINDOW) cnt = SPEC_WINDOW;
         if (lane == j) my_base = base;
         if (lane >= base && lane < base + cnt) {
           tj = j;
@@ -421,11 +432,14 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
     int k_ev = -1;
     bool ev_inside = false;
     double ev_mu = 0.0;
+    int scan_from = j + 1; /* first piece not covered by the speculation */
     if (spec) {
       int cntj = n - 1 - j;
+      if (cntj > SPEC_WINDOW) cntj = SPEC_WINDOW;
+      scan_from = j + 1 + cntj;
       if (cntj > 0) {
         int base = rdlane_i(my_base, j);
-        unsigned long long range = (cntj >= 64 ? ~0ull : ((1ull << cntj) - 1ull)) << base;
+        unsigned long long range = ((1ull << cntj) - 1ull) << base;
         unsigned long long ev = sp_ev & range;
         unsigned long long visited = ev ? (range & lanes_below(ctz64(ev))) : range;
         if (sp_bad & visited) err |= WERR_REF_THROW;
@@ -436,8 +450,9 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
           ev_mu = rdlane_d(sp_mu, src);
         }
       }
-    } else {
-      for (int base = j + 1; base < n; base += WAVE) {
+    }
+    if (k_ev < 0) { /* pieces beyond the speculation window: scan them now */
+      for (int base = scan_from; base < n; base += WAVE) {
         int k = base + lane;
         bool inside = false, at_right = false, bad = false;
         double mu = PSD_INF;
@@ -560,12 +575,16 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, S s, int data_i_out)
   if (small) {
     unsigned long long m_start = ballot(lane < n && P.cls != CLS_STORE);
     int total = 0;
-    for (unsigned long long m = m_start; m; m &= m - 1) total += ctz64(m);
+    for (unsigned long long m = m_start; m; m &= m - 1) {
+      int c = ctz64(m);
+      total += c < SPEC_WINDOW ? c : SPEC_WINDOW;
+    }
     if (total > 0 && total <= WAVE) {
       spec = true;
       int tj = -1, tk = 0, base = 0;
       for (unsigned long long m = m_start; m; m &= m - 1) {
         int j = ctz64(m), cnt = j;
+        if (cnt > SPEC_WINDOW) cnt = SPEC_WINDOW;
         if (lane == j) my_base = base;
         if (lane >= base && lane < base + cnt) {
           tj = j;
@@ -648,10 +667,13 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, S s, int data_i_out)
     int k_ev = -1;
     bool ev_inside = false;
     double ev_mu = 0.0;
+    int scan_from = j - 1; /* first piece (walking down) not covered by the speculation */
     if (spec) {
-      if (j > 0) {
+      int cntj = j < SPEC_WINDOW ? j : SPEC_WINDOW;
+      scan_from = j - 1 - cntj;
+      if (cntj > 0) {
         int base = rdlane_i(my_base, j);
-        unsigned long long range = (j >= 64 ? ~0ull : ((1ull << j) - 1ull)) << base;
+        unsigned long long range = ((1ull << cntj) - 1ull) << base;
         unsigned long long ev = sp_ev & range;
         if (ev) {
           int src = ctz64(ev);
@@ -660,8 +682,9 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, S s, int data_i_out)
           ev_mu = rdlane_d(sp_mu, src);
         }
       }
-    } else {
-      for (int base = j - 1; base >= 0; base -= WAVE) {
+    }
+    if (k_ev < 0) { /* pieces beyond the speculation window: scan them now */
+      for (int base = scan_from; base >= 0; base -= WAVE) {
         int k = base - lane;
         bool inside = false, at_left = false;
         double mu = PSD_INF;
