@@ -118,28 +118,6 @@ PSD_D GlobalScratch global_scratch(const DeviceArgs &a, int p, int wave) {
   return r;
 }
 
-/* f <- (f * cum_weight_prev + (weight, -coverage*weight, 0)) * (1/cum_weight)
- * exactly as drv:316-321 / 365-370: multiply, add, multiply, no contraction. */
-template <class L>
-PSD_D void scale_add_wave(const L &f, int n, double cum_weight_prev, double add_linear,
-                          double add_log, double inv_cum_weight) {
-  const int lane = lane_id();
-  for (int base = 0; base < n; base += WAVE) {
-    int i = base + lane;
-    if (i < n) {
-      double li = f.Lin(i) * cum_weight_prev;
-      double lo = f.Log(i) * cum_weight_prev;
-      double co = f.Con(i) * cum_weight_prev;
-      li = li + add_linear;
-      lo = lo + add_log;
-      co = co + 0.0;
-      f.Lin(i) = li * inv_cum_weight;
-      f.Log(i) = lo * inv_cum_weight;
-      f.Con(i) = co * inv_cum_weight;
-    }
-  }
-}
-
 template <class L>
 PSD_D void copy_list_wave(const L &src, int n, const L &dst) {
   const int lane = lane_id();
@@ -164,7 +142,7 @@ PSD_D bool arena_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &f, i
     int chunks = (n + ARENA_CHUNK - 1) >> ARENA_CHUNK_LOG2;
     unsigned long long first = 0;
     if (lane == 0) first = atomicAdd(a.ar_next_chunk, (unsigned long long)chunks);
-    first = psd_d2u(shfl_d(psd_u2d(first), 0));
+    first = psd_d2u(rdlane_d(psd_u2d(first), 0));
     cur.base = first << ARENA_CHUNK_LOG2;
     cur.used = 0;
     cur.room = chunks << ARENA_CHUNK_LOG2;
@@ -268,7 +246,7 @@ PSD_D void minimize_wave(const L &f, int n, double *best_cost, double *best_log_
     if (m && mn < bc) {
       int src = ctz64(m);
       bc = mn;
-      blm = shfl_d(lm, src);
+      blm = rdlane_d(lm, src);
       int ii = base + src;
       bdi = f.di(ii);
       bprv = f.prv(ii);
@@ -566,8 +544,8 @@ __global__ __launch_bounds__(64) void fpop_backtrack_kernel(DeviceArgs a) {
       unsigned long long m = ballot(hit);
       if (m) {
         int src = ctz64(m);
-        prev_seg_end = shfl_i(di, src);
-        prev_log_mean = shfl_d(prv, src);
+        prev_seg_end = rdlane_i(di, src);
+        prev_log_mean = rdlane_d(prv, src);
         found = true;
         break;
       }

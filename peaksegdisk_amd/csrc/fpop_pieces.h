@@ -152,7 +152,7 @@ PSD_COLD_DEV double larger_root_full(const Coef &c, double optimal_mean, double 
 /* fpl:69-127: larger root, returned as a log-mean.
  * right_cost = getCost(max_log_mean), supplied by the caller. */
 PSD_D double get_larger_root(const Coef &c, const PieceOpt &o, double max_log_mean,
-                             double right_cost, double equals) {
+                             double right_cost, double equals, int *steps_out = nullptr) {
   double optimal_mean = o.mean;
   double optimal_cost = o.cost2;
   if ((optimal_cost < right_cost && right_cost < equals) ||
@@ -168,6 +168,7 @@ PSD_D double get_larger_root(const Coef &c, const PieceOpt &o, double max_log_me
     double deriv = c.Linear + c.Log / candidate_root; /* PoissonDeriv fpl:63-65 */
     candidate_root = candidate_root - candidate_cost / deriv;
   } while (NEWTON_EPSILON < absd(candidate_cost));
+  if (steps_out) *steps_out = step;
   return d_log(candidate_root);
 }
 
@@ -217,7 +218,7 @@ PSD_COLD_DEV double smaller_root_full(const Coef &c, double optimal_log_mean,
 /* fpl:129-190: smaller root (a log-mean).
  * left_cost = getCost(min_log_mean), supplied by the caller. */
 PSD_D double get_smaller_root(const Coef &c, const PieceOpt &o, double min_log_mean,
-                              double left_cost, double equals) {
+                              double left_cost, double equals, int *steps_out = nullptr) {
   double optimal_log_mean = o.log_mean;
   double optimal_cost = o.cost;
   if ((equals < left_cost && left_cost < optimal_cost) ||
@@ -240,6 +241,7 @@ PSD_D double get_smaller_root(const Coef &c, const PieceOpt &o, double min_log_m
     double offset = candidate_cost / deriv;
     candidate_root = candidate_root - offset;
   } while (NEWTON_EPSILON < absd(candidate_cost));
+  if (steps_out) *steps_out = step;
   return candidate_root;
 }
 

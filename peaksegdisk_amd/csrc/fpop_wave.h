@@ -53,7 +53,7 @@ struct ScratchStore {
   int cls[LDS_CAP];
   int iv[2 * LDS_CAP];
 };
-constexpr int N_PROF = 16;
+constexpr int N_PROF = 20;
 /* the workgroup's LDS: lists 0,1 = up (double-buffered), 2,3 = down, 4,5 = per-wave
  * min-less / min-more result */
 struct SharedBlock {
@@ -92,8 +92,21 @@ enum {
   PROF_PRE = 0, PROF_WALK = 1, PROF_TABLE = 2, PROF_CLASSIFY = 3, PROF_COMPACT = 4,
   PROF_SCALE = 5, PROF_ARENA = 6, PROF_BARRIER = 7, PROF_SERIAL = 8, PROF_TOTAL = 9,
   PROF_C_LOAD = 10, PROF_C_MID = 11, PROF_C_OPT = 12, PROF_C_SMALL = 13, PROF_C_LARGE = 14,
-  PROF_C_TAIL = 15
+  PROF_C_TAIL = 15,
+  PROF_IT_SPEC = 16, PROF_IT_SMALL = 17, PROF_IT_LARGE = 18 /* wave-level Newton trip counts */
 };
+#ifdef PSD_PROFILE
+#define PSD_PROF_ITERS(slot, steps)                                 \
+  do {                                                              \
+    int m_ = 0;                                                     \
+    while (ballot((steps) > m_)) m_++;                              \
+    if (lane_id() == 0) g_sm.prof[wave_id()][slot] += m_;           \
+  } while (0)
+#else
+#define PSD_PROF_ITERS(slot, steps) \
+  do {                             \
+  } while (0)
+#endif
 
 /* accessor of an LDS-resident list: g_sm.list[id], elements off.. */
 struct LdsList {
@@ -352,6 +365,7 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
         base += cnt;
       }
       bool inside = false, at_right = false, bad = false;
+      int sp_steps = 0;
       if (tj >= 0) {
         double level = (s.cls(tj) == CLS_CONST_MU) ? s.muc(tj) : s.lc(tj);
         Coef c = load_coef(in, tk);
@@ -360,12 +374,13 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
         } else {
           PieceOpt o = {s.om(tk), s.mu(tk), s.muc(tk), s.oc2(tk)};
           if (has_two_roots(c, o, level)) {
-            sp_mu = get_smaller_root(c, o, in.mn(tk), s.lc(tk), level);
+            sp_mu = get_smaller_root(c, o, in.mn(tk), s.lc(tk), level, &sp_steps);
             inside = in.mn(tk) < sp_mu && sp_mu < in.mx(tk);
           }
           if (!inside) at_right = s.rc(tk) <= level + NEWTON_EPSILON;
         }
       }
+      PSD_PROF_ITERS(PROF_IT_SPEC, sp_steps);
       sp_ev = ballot(inside || at_right);
       sp_inside = ballot(inside);
       sp_bad = ballot(bad);
@@ -593,6 +608,7 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, S s, int data_i_out)
         base += cnt;
       }
       bool inside = false, at_left = false;
+      int sp_steps = 0;
       if (tj >= 0) {
         double level = (s.cls(tj) == CLS_CONST_MU) ? s.muc(tj) : s.rc(tj);
         Coef c = load_coef(in, tk);
@@ -601,12 +617,13 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, S s, int data_i_out)
         } else {
           PieceOpt o = {s.om(tk), s.mu(tk), s.muc(tk), s.oc2(tk)};
           if (has_two_roots(c, o, level)) {
-            sp_mu = get_larger_root(c, o, in.mx(tk), s.rc(tk), level);
+            sp_mu = get_larger_root(c, o, in.mx(tk), s.rc(tk), level, &sp_steps);
           }
         }
         inside = in.mn(tk) < sp_mu && sp_mu < in.mx(tk);
         if (!inside) at_left = s.lc(tk) <= level + NEWTON_EPSILON;
       }
+      PSD_PROF_ITERS(PROF_IT_SPEC, sp_steps);
       sp_ev = ballot(inside || at_left);
       sp_inside = ballot(inside);
     }
@@ -1063,10 +1080,13 @@ PSD_D void env_classify_lanes(bool valid, const Coef &c1, const Coef &c2, double
   PSD_PROF_ADD(PROF_C_OPT);
   /* phases E, F: the two Newton solves (fpl:1023-1028) */
   double smaller_log_mean = PSD_INF, larger_log_mean = PSD_INF;
-  if (two_roots) smaller_log_mean = get_smaller_root(d, o, a, cost_diff_left, 0.0);
+  int it_small = 0, it_large = 0;
+  if (two_roots) smaller_log_mean = get_smaller_root(d, o, a, cost_diff_left, 0.0, &it_small);
   PSD_PROF_ADD(PROF_C_SMALL);
-  if (two_roots) larger_log_mean = get_larger_root(d, o, b, cost_diff_right, 0.0);
+  if (two_roots) larger_log_mean = get_larger_root(d, o, b, cost_diff_right, 0.0, &it_large);
   PSD_PROF_ADD(PROF_C_LARGE);
+  PSD_PROF_ITERS(PROF_IT_SMALL, it_small);
+  PSD_PROF_ITERS(PROF_IT_LARGE, it_large);
   /* phase G..: only intervals equal on neither side need more evaluations (fpl:1124-1258) */
   const bool neither = rootp && !same_at_left && !same_at_right;
   double e_smaller = 0.0;

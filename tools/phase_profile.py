@@ -16,8 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 NAMES = ["pre(costs+classes)", "walk(state machine+roots)", "env table", "env classify",
          "env compact", "scale_add", "arena", "barrier wait", "env serial", "TOTAL",
-         "c.load", "c.mid", "c.opt", "c.small", "c.large", "c.tail"]
-NP = 16
+         "c.load", "c.mid", "c.opt", "c.small", "c.large", "c.tail",
+         "it.spec", "it.small", "it.large", "-"]
+NP = 20
 
 
 def main():
@@ -50,7 +51,9 @@ def main():
             v = buf[w * NP:(w + 1) * NP]
             tot = float(v[9])
             shares = " ".join("%s=%.1f%%" % (NAMES[i].split("(")[0], 100.0 * v[i] / tot)
-                              for i in list(range(9)) + list(range(10, NP)))
+                              for i in list(range(9)) + list(range(10, 16)))
+            shares += " | wave-level Newton trips per step: spec=%.1f small=%.1f large=%.1f" % (
+                v[16] / bins, v[17] / bins, v[18] / bins)
             print("pen=%-18s wave%d cyc/step=%7.0f mean_int=%.2f | %s" % (
                 pens[p], w, tot / bins, r.total_intervals / (2.0 * bins), shares))
     pset.close()
