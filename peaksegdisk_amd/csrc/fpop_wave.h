@@ -1309,20 +1309,22 @@ PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap, S s) {
     int p = 0;
     bool dup = false;
     if (valid) x = own.mx(idx);
-    const int n_max = n1 > n2 ? n1 : n2;
-    double at_p = 0.0;
-    for (int j = 0; j < n_max; j++) {
-      if (valid && j < n_oth) {
-        double v = oth.mx(j);
-        if (v < x) {
-          p++;
-        } else if (v == x) {
-          at_p = v;
-          dup = true;
+    /* the other list's ends, eight independent LDS reads per round trip */
+    for (int j0 = 0; j0 < n_oth; j0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        int j = j0 + u;
+        v[u] = oth.mx(j < n_oth ? j : n_oth - 1);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        if (valid && j0 + u < n_oth) {
+          p += v[u] < x ? 1 : 0;
+          dup = dup || v[u] == x;
         }
       }
     }
-    (void)at_p;
     unsigned long long md = ballot(dup);
     const unsigned long long half = side ? (md >> 32) : (md & 0xffffffffull);
     if (valid && !(side && dup)) {
