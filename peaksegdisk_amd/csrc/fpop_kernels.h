@@ -286,6 +286,7 @@ PSD_D int chain_step(const DeviceArgs &a, ArenaCursor &cur, unsigned long long f
   } else if (t >= 2) {
     nm = min_more_wave(other_prev, n_other, mlist, cap, sc, t - 1);
   }
+  nm = uniform_i(nm); /* return values of out-of-line functions arrive in a VGPR */
   if (nm < 0) return nm;
   int n_new;
   if (t == 1) {
@@ -298,7 +299,7 @@ PSD_D int chain_step(const DeviceArgs &a, ArenaCursor &cur, unsigned long long f
     }
   } else {
     const L f1 = chain == 0 ? mlist : mlist.shifted(cap - nm);
-    n_new = min_env_wave(f1, nm, own_prev, n_own, own_new, cap, sc);
+    n_new = uniform_i(min_env_wave(f1, nm, own_prev, n_own, own_new, cap, sc));
   }
   if (n_new < 0) return n_new;
   PSD_PROF_T0();
@@ -317,7 +318,7 @@ PSD_D int chain_step(const DeviceArgs &a, ArenaCursor &cur, unsigned long long f
  * have shrunk below LDS_CAP/2. */
 __global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
   const int p = (int)blockIdx.x;
-  const int chain = wave_id();
+  const int chain = uniform_i(wave_id()); /* uniform per wave: say so (scalar branches) */
   const int lane = lane_id();
   const int contig = a.prob_contig[p];
   const int N = a.contig_n[contig];
@@ -366,8 +367,8 @@ __global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
       cnt_reg = tt < N ? count[tt] : 0;
       wt_reg = tt < N ? weight[tt] : 0;
     }
-    const int coverage = shfl_i(cnt_reg, t & 63);
-    const double w = (double)shfl_i(wt_reg, t & 63);
+    const int coverage = rdlane_i(cnt_reg, t & 63);
+    const double w = (double)rdlane_i(wt_reg, t & 63);
     const double cum_weight_new = cum_weight_i + w;
     const int nb = b ^ 1;
     const int id_own_prev = 2 * chain + b, id_own_new = 2 * chain + nb;

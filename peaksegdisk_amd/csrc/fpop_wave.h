@@ -93,7 +93,8 @@ enum {
   PROF_SCALE = 5, PROF_ARENA = 6, PROF_BARRIER = 7, PROF_SERIAL = 8, PROF_TOTAL = 9,
   PROF_C_LOAD = 10, PROF_C_MID = 11, PROF_C_OPT = 12, PROF_C_SMALL = 13, PROF_C_LARGE = 14,
   PROF_C_TAIL = 15,
-  PROF_IT_SPEC = 16, PROF_IT_SMALL = 17, PROF_IT_LARGE = 18 /* wave-level Newton trip counts */
+  PROF_IT_SPEC = 16, PROF_IT_SMALL = 17, PROF_IT_LARGE = 18, /* wave-level Newton trip counts */
+  PROF_IT_ROUNDS = 19 /* walk state-machine rounds */
 };
 #ifdef PSD_PROFILE
 #define PSD_PROF_ITERS(slot, steps)                                 \
@@ -105,6 +106,16 @@ enum {
 #else
 #define PSD_PROF_ITERS(slot, steps) \
   do {                             \
+  } while (0)
+#endif
+#ifdef PSD_PROFILE
+#define PSD_PROF_COUNT(slot)                                       \
+  do {                                                             \
+    if (lane_id() == 0) g_sm.prof[wave_id()][slot] += 1;           \
+  } while (0)
+#else
+#define PSD_PROF_COUNT(slot) \
+  do {                       \
   } while (0)
 #endif
 
@@ -124,6 +135,15 @@ struct LdsList {
     r.off = off + d;
     return r;
   }
+  /* Arguments of out-of-line device functions arrive in VGPRs and the compiler must assume
+   * they differ between lanes: every loop and branch on them becomes an exec-mask loop.  They
+   * are wave-uniform by construction; readfirstlane says so. */
+  PSD_M LdsList uniformed() const {
+    LdsList r;
+    r.id = uniform_i(id);
+    r.off = uniform_i(off);
+    return r;
+  }
 };
 /* accessor of a wave's LDS scratch arrays */
 struct LdsScratch {
@@ -137,6 +157,11 @@ struct LdsScratch {
   PSD_M int &cls(int i) const { return g_sm.sc[w].cls[i]; }
   PSD_M int &iv(int i) const { return g_sm.sc[w].iv[i]; }
   PSD_M int iv_cap() const { return 2 * LDS_CAP; }
+  PSD_M LdsScratch uniformed() const {
+    LdsScratch r;
+    r.w = uniform_i(w);
+    return r;
+  }
 };
 
 /* The same two accessors over HBM: the spill path for functions with more than LDS_CAP
@@ -162,6 +187,17 @@ struct GlobalList {
     r.di_ = di_ + d;
     return r;
   }
+  PSD_M GlobalList uniformed() const {
+    GlobalList r;
+    r.Lin_ = uniform_p(Lin_);
+    r.Log_ = uniform_p(Log_);
+    r.Con_ = uniform_p(Con_);
+    r.mn_ = uniform_p(mn_);
+    r.mx_ = uniform_p(mx_);
+    r.prv_ = uniform_p(prv_);
+    r.di_ = uniform_p(di_);
+    return r;
+  }
 };
 struct GlobalScratch {
   double *lc_, *rc_, *om_, *mu_, *muc_, *oc2_;
@@ -176,6 +212,19 @@ struct GlobalScratch {
   PSD_M int &cls(int i) const { return cls_[i]; }
   PSD_M int &iv(int i) const { return iv_[i]; }
   PSD_M int iv_cap() const { return iv_cap_; }
+  PSD_M GlobalScratch uniformed() const {
+    GlobalScratch r;
+    r.lc_ = uniform_p(lc_);
+    r.rc_ = uniform_p(rc_);
+    r.om_ = uniform_p(om_);
+    r.mu_ = uniform_p(mu_);
+    r.muc_ = uniform_p(muc_);
+    r.oc2_ = uniform_p(oc2_);
+    r.cls_ = uniform_p(cls_);
+    r.iv_ = uniform_p(iv_);
+    r.iv_cap_ = uniform_i(iv_cap_);
+    return r;
+  }
 };
 
 PSD_D LdsList lds_list(int id) {
@@ -278,8 +327,12 @@ PSD_D void piece_costs_wave(const L &in, int n, const S &s, LanePiece &P) {
  * driver's set_prev_seg_end) and Constant += add_const (its add(0,0,penalty/cum_weight_prev),
  * PeakSegFPOPLog.cpp:290-296). */
 template <class L, class S>
-PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
-                               double add_const) {
+PSD_NOINLINE int min_less_wave(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
+                               double add_const_) {
+  const L in = in_.uniformed(), out = out_.uniformed();
+  const S s = s_.uniformed();
+  const int n = uniform_i(n_), cap = uniform_i(cap_), data_i_out = uniform_i(data_i_out_);
+  const double add_const = uniform_d(add_const_);
   const int lane = lane_id();
   const bool small = n <= WAVE; /* lane i holds piece i */
   LanePiece P;
@@ -390,7 +443,15 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
   int n_out = 0;
   int i0 = 0;
   double prev_min_log_mean = mn_at(0);
+  /* Functions of at most 64 pieces: the walk only RECORDS, in the lane of each input piece,
+   * what that piece contributes (first its own kept or partial convex piece, then the
+   * constant that starts at it); everything is written in one parallel pass after the
+   * walk.  Longer functions write as they go. */
+  bool e1 = false, e2 = false;          /* this lane's piece emits a convex / a constant piece */
+  double e1_lo = 0.0, e1_hi = 0.0;      /* convex piece: own coefficients on [e1_lo, e1_hi] */
+  double e2_lo = 0.0, e2_hi = 0.0, e2_level = 0.0, e2_best = 0.0;
   for (;;) {
+    PSD_PROF_COUNT(PROF_IT_ROUNDS);
     /* ---- search mode: first piece j >= i0 that starts a constant ---- */
     int j = n;
     for (int base = i0 & ~(WAVE - 1); base < n; base += WAVE) {
@@ -405,21 +466,27 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
     }
     /* pieces i0..j-1 are kept as they are (fpl:303-307,361-364) */
     int cnt = j - i0;
-    if (n_out + cnt + 2 > cap) return -WERR_OVERFLOW;
-    for (int base = i0; base < j; base += (small ? n : WAVE)) {
-      int i = small ? lane : base + lane;
-      if (i >= i0 && i < j) {
-        Coef c = small ? P.c : load_coef(in, i);
-        c.Constant = c.Constant + add_const;
-        c.Linear = c.Linear + 0.0;
-        c.Log = c.Log + 0.0;
-        double mn_i = small ? P.mn : in.mn(i);
-        double mx_i = small ? P.mx : in.mx(i);
-        double lo = (i == i0) ? prev_min_log_mean : mn_i;
-        store_piece(out, n_out + (i - i0), c, lo, mx_i, data_i_out, PSD_INF);
+    if (small) {
+      if (lane >= i0 && lane < j) {
+        e1 = true;
+        e1_lo = (lane == i0) ? prev_min_log_mean : P.mn;
+        e1_hi = P.mx;
       }
+    } else {
+      if (n_out + cnt + 2 > cap) return -WERR_OVERFLOW;
+      for (int base = i0; base < j; base += WAVE) {
+        int i = base + lane;
+        if (i < j) {
+          Coef c = load_coef(in, i);
+          c.Constant = c.Constant + add_const;
+          c.Linear = c.Linear + 0.0;
+          c.Log = c.Log + 0.0;
+          double lo = (i == i0) ? prev_min_log_mean : in.mn(i);
+          store_piece(out, n_out + (i - i0), c, lo, in.mx(i), data_i_out, PSD_INF);
+        }
+      }
+      n_out += cnt;
     }
-    n_out += cnt;
     if (cnt > 0) prev_min_log_mean = mx_at(j - 1);
     if (j == n) break;
     /* ---- piece j starts a constant piece ---- */
@@ -427,14 +494,22 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
     if (cls_at(j) == CLS_CONST_MU) { /* fpl:337-355 */
       double mu = mu_at(j);
       if (prev_min_log_mean < mu) {
-        if (lane == 0) {
-          Coef c = load_coef(in, j);
-          c.Constant = c.Constant + add_const;
-          c.Linear = c.Linear + 0.0;
-          c.Log = c.Log + 0.0;
-          store_piece(out, n_out, c, prev_min_log_mean, mu, data_i_out, PSD_INF);
+        if (small) {
+          if (lane == j) {
+            e1 = true;
+            e1_lo = prev_min_log_mean;
+            e1_hi = mu;
+          }
+        } else {
+          if (lane == 0) {
+            Coef c = load_coef(in, j);
+            c.Constant = c.Constant + add_const;
+            c.Linear = c.Linear + 0.0;
+            c.Log = c.Log + 0.0;
+            store_piece(out, n_out, c, prev_min_log_mean, mu, data_i_out, PSD_INF);
+          }
+          n_out++;
         }
-        n_out++;
       }
       prev_min_log_mean = mu;
       prev_best_log_mean = mu;
@@ -503,28 +578,59 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
     cc.Linear = 0.0 + 0.0;
     cc.Log = 0.0 + 0.0;
     cc.Constant = prev_min_cost + add_const;
-    if (k_ev < 0) { /* constant runs to the end (fpl:429-436) */
-      double mx_last = mx_at(n - 1);
-      if (lane == 0)
-        store_piece(out, n_out, cc, prev_min_log_mean, mx_last, data_i_out,
-                    prev_best_log_mean);
-      n_out++;
-      break;
-    }
-    if (ev_inside) { /* crossing inside piece k: revisit k in search mode (fpl:397-408) */
-      if (lane == 0)
-        store_piece(out, n_out, cc, prev_min_log_mean, ev_mu, data_i_out, prev_best_log_mean);
-      n_out++;
-      prev_min_log_mean = ev_mu;
+    /* where the constant ends: the end of the function (fpl:429-436), a crossing inside piece
+     * k, which is then revisited in search mode (fpl:397-408), or the right end of piece k
+     * (fpl:410-420) */
+    double c_hi;
+    bool last_round = false;
+    if (k_ev < 0) {
+      c_hi = mx_at(n - 1);
+      last_round = true;
+    } else if (ev_inside) {
+      c_hi = ev_mu;
       i0 = k_ev;
-    } else { /* constant ends on the right end of piece k (fpl:410-420) */
-      double mxk = mx_at(k_ev);
-      if (lane == 0)
-        store_piece(out, n_out, cc, prev_min_log_mean, mxk, data_i_out, prev_best_log_mean);
-      n_out++;
-      prev_min_log_mean = mxk;
+    } else {
+      c_hi = mx_at(k_ev);
       i0 = k_ev + 1;
-      if (i0 == n) break;
+      if (i0 == n) last_round = true;
+    }
+    if (small) {
+      if (lane == j) {
+        e2 = true;
+        e2_lo = prev_min_log_mean;
+        e2_hi = c_hi;
+        e2_level = cc.Constant;
+        e2_best = prev_best_log_mean;
+      }
+    } else {
+      if (lane == 0)
+        store_piece(out, n_out, cc, prev_min_log_mean, c_hi, data_i_out, prev_best_log_mean);
+      n_out++;
+    }
+    prev_min_log_mean = c_hi;
+    if (last_round) break;
+  }
+  if (small) {
+    /* one parallel pass: lane i writes its convex piece, then its constant piece */
+    unsigned long long m1 = ballot(e1), m2 = ballot(e2);
+    unsigned long long lb = lanes_below(lane);
+    n_out = popc64(m1) + popc64(m2);
+    if (n_out + 2 > cap) return -WERR_OVERFLOW;
+    int pos = popc64(m1 & lb) + popc64(m2 & lb);
+    if (e1) {
+      Coef c = P.c;
+      c.Constant = c.Constant + add_const;
+      c.Linear = c.Linear + 0.0;
+      c.Log = c.Log + 0.0;
+      store_piece(out, pos, c, e1_lo, e1_hi, data_i_out, PSD_INF);
+      pos++;
+    }
+    if (e2) {
+      Coef cc;
+      cc.Linear = 0.0 + 0.0;
+      cc.Log = 0.0 + 0.0;
+      cc.Constant = e2_level;
+      store_piece(out, pos, cc, e2_lo, e2_hi, data_i_out, e2_best);
     }
   }
   wave_sync();
@@ -536,7 +642,10 @@ PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
 /* min-more: out(x) = min_{y>=x} in(y).  The reference builds the list with emplace_front;
  * here pieces are written downwards from out[cap-1]: the result is out[cap-n .. cap). */
 template <class L, class S>
-PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, S s, int data_i_out) {
+PSD_NOINLINE int min_more_wave(L in_, int n_, L out_, int cap_, S s_, int data_i_out_) {
+  const L in = in_.uniformed(), out = out_.uniformed();
+  const S s = s_.uniformed();
+  const int n = uniform_i(n_), cap = uniform_i(cap_), data_i_out = uniform_i(data_i_out_);
   const int lane = lane_id();
   const bool small = n <= WAVE;
   LanePiece P;
@@ -632,7 +741,14 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, S s, int data_i_out)
   int n_out = 0; /* pieces written so far; piece p lives at out[cap-1-p] */
   int i0 = n - 1;
   double prev_max_log_mean = mx_at(n - 1);
+  /* deferred emission for functions of at most 64 pieces, as in min_less_wave; in ascending
+   * order a piece contributes first the constant that starts at it (it extends downwards),
+   * then its own kept or partial convex piece */
+  bool e1 = false, e2 = false;
+  double e1_lo = 0.0, e1_hi = 0.0;
+  double e2_lo = 0.0, e2_hi = 0.0, e2_level = 0.0, e2_best = 0.0;
   for (;;) {
+    PSD_PROF_COUNT(PROF_IT_ROUNDS);
     /* ---- search mode, walking down from i0: first piece j <= i0 starting a constant ---- */
     int j = -1;
     if (small) {
@@ -650,28 +766,42 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, S s, int data_i_out)
       }
     }
     int cnt = i0 - j;
-    if (n_out + cnt + 2 > cap) return -WERR_OVERFLOW;
-    for (int base = i0; base > j; base -= (small ? n : WAVE)) {
-      int i = small ? lane : base - lane;
-      if (i > j && i <= i0) {
-        Coef c = small ? P.c : load_coef(in, i);
-        double mn_i = small ? P.mn : in.mn(i);
-        double mx_i = small ? P.mx : in.mx(i);
-        double hi = (i == i0) ? prev_max_log_mean : mx_i;
-        store_piece(out, cap - 1 - (n_out + (i0 - i)), c, mn_i, hi, data_i_out, PSD_INF);
+    if (small) {
+      if (lane > j && lane <= i0) {
+        e1 = true;
+        e1_lo = P.mn;
+        e1_hi = (lane == i0) ? prev_max_log_mean : P.mx;
       }
+    } else {
+      if (n_out + cnt + 2 > cap) return -WERR_OVERFLOW;
+      for (int base = i0; base > j; base -= WAVE) {
+        int i = base - lane;
+        if (i > j) {
+          Coef c = load_coef(in, i);
+          double hi = (i == i0) ? prev_max_log_mean : in.mx(i);
+          store_piece(out, cap - 1 - (n_out + (i0 - i)), c, in.mn(i), hi, data_i_out, PSD_INF);
+        }
+      }
+      n_out += cnt;
     }
-    n_out += cnt;
     if (cnt > 0) prev_max_log_mean = mn_at(j + 1);
     if (j < 0) break;
     double prev_min_cost, prev_best_log_mean;
     if (cls_at(j) == CLS_CONST_MU) { /* fpl:524-537 */
       double mu = mu_at(j);
       if (mu < prev_max_log_mean) {
-        if (lane == 0)
-          store_piece(out, cap - 1 - n_out, load_coef(in, j), mu, prev_max_log_mean, data_i_out,
-                      PSD_INF);
-        n_out++;
+        if (small) {
+          if (lane == j) {
+            e1 = true;
+            e1_lo = mu;
+            e1_hi = prev_max_log_mean;
+          }
+        } else {
+          if (lane == 0)
+            store_piece(out, cap - 1 - n_out, load_coef(in, j), mu, prev_max_log_mean,
+                        data_i_out, PSD_INF);
+          n_out++;
+        }
       }
       prev_max_log_mean = mu;
       prev_best_log_mean = mu;
@@ -733,31 +863,55 @@ PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, S s, int data_i_out)
     cc.Linear = 0.0;
     cc.Log = 0.0;
     cc.Constant = prev_min_cost;
-    if (k_ev < 0) { /* constant runs to the start (fpl:608-615) */
-      double mn_first = mn_at(0);
-      if (lane == 0)
-        store_piece(out, cap - 1 - n_out, cc, mn_first, prev_max_log_mean, data_i_out,
-                    prev_best_log_mean);
-      n_out++;
-      break;
-    }
-    if (ev_inside) { /* fpl:578-590 */
-      if (lane == 0)
-        store_piece(out, cap - 1 - n_out, cc, ev_mu, prev_max_log_mean, data_i_out,
-                    prev_best_log_mean);
-      n_out++;
-      prev_max_log_mean = ev_mu;
+    /* where the constant ends (walking down): the start of the function (fpl:608-615), a
+     * crossing inside piece k, then revisited (fpl:578-590), or the left end of piece k
+     * (fpl:591-601) */
+    double c_lo;
+    bool last_round = false;
+    if (k_ev < 0) {
+      c_lo = mn_at(0);
+      last_round = true;
+    } else if (ev_inside) {
+      c_lo = ev_mu;
       i0 = k_ev;
-    } else { /* fpl:591-601 */
-      double mnk = mn_at(k_ev);
+    } else {
+      c_lo = mn_at(k_ev);
+      i0 = k_ev - 1;
+      if (i0 < 0) last_round = true;
+    }
+    if (small) {
+      if (lane == j) {
+        e2 = true;
+        e2_lo = c_lo;
+        e2_hi = prev_max_log_mean;
+        e2_level = prev_min_cost;
+        e2_best = prev_best_log_mean;
+      }
+    } else {
       if (lane == 0)
-        store_piece(out, cap - 1 - n_out, cc, mnk, prev_max_log_mean, data_i_out,
+        store_piece(out, cap - 1 - n_out, cc, c_lo, prev_max_log_mean, data_i_out,
                     prev_best_log_mean);
       n_out++;
-      prev_max_log_mean = mnk;
-      i0 = k_ev - 1;
-      if (i0 < 0) break;
     }
+    prev_max_log_mean = c_lo;
+    if (last_round) break;
+  }
+  if (small) {
+    /* one parallel pass; the result occupies out[cap-n_out .. cap) in ascending order */
+    unsigned long long m1 = ballot(e1), m2 = ballot(e2);
+    unsigned long long lb = lanes_below(lane);
+    n_out = popc64(m1) + popc64(m2);
+    if (n_out + 2 > cap) return -WERR_OVERFLOW;
+    int pos = cap - n_out + popc64(m1 & lb) + popc64(m2 & lb);
+    if (e2) {
+      Coef cc;
+      cc.Linear = 0.0;
+      cc.Log = 0.0;
+      cc.Constant = e2_level;
+      store_piece(out, pos, cc, e2_lo, e2_hi, data_i_out, e2_best);
+      pos++;
+    }
+    if (e1) store_piece(out, pos, P.c, e1_lo, e1_hi, data_i_out, PSD_INF);
   }
   wave_sync();
   PSD_PROF_ADD(PROF_WALK);
@@ -1250,7 +1404,10 @@ PSD_D bool bit_identical(const Coef &last, double last_prv, int last_di, const C
 
 /* exact sequential replay of fpl:832-860 + push_piece on lane 0 (cold path) */
 template <class L, class S>
-PSD_NOINLINE int min_env_serial(L f1, int n1, L f2, int n2, L out, int cap, S s, int K) {
+PSD_NOINLINE int min_env_serial(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, int K_) {
+  const L f1 = f1_.uniformed(), f2 = f2_.uniformed(), out = out_.uniformed();
+  const S s = s_.uniformed();
+  const int n1 = uniform_i(n1_), n2 = uniform_i(n2_), cap = uniform_i(cap_), K = uniform_i(K_);
   const int lane = lane_id();
   int count = 0;
   int err = 0;
@@ -1291,7 +1448,10 @@ PSD_NOINLINE int min_env_serial(L f1, int n1, L f2, int n2, L out, int cap, S s,
 
 /* min-envelope: out = pointwise min(f1, f2). */
 template <class L, class S>
-PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap, S s) {
+PSD_NOINLINE int min_env_wave(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_) {
+  const L f1 = f1_.uniformed(), f2 = f2_.uniformed(), out = out_.uniformed();
+  const S s = s_.uniformed();
+  const int n1 = uniform_i(n1_), n2 = uniform_i(n2_), cap = uniform_i(cap_);
   const int lane = lane_id();
   const int iv_cap = s.iv_cap();
   PSD_PROF_T0();

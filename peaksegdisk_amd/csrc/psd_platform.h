@@ -94,6 +94,18 @@ PSD_D long long cycle_now() { return 0; }
 PSD_D long long cycle_now() { return (long long)__builtin_readcyclecounter(); }
 #endif
 
+template <class T>
+PSD_D T *uniform_p(T *p) {
+#ifdef PSD_EMU
+  return p;
+#else
+  uint64_t u = (uint64_t)p;
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+  return (T *)(((uint64_t)hi << 32) | lo);
+#endif
+}
+
 PSD_D int popc64(unsigned long long m) { return __builtin_popcountll(m); }
 /* index of the lowest set bit; m != 0 */
 PSD_D int ctz64(unsigned long long m) { return __builtin_ctzll(m); }

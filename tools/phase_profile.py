@@ -52,8 +52,8 @@ def main():
             tot = float(v[9])
             shares = " ".join("%s=%.1f%%" % (NAMES[i].split("(")[0], 100.0 * v[i] / tot)
                               for i in list(range(9)) + list(range(10, 16)))
-            shares += " | wave-level Newton trips per step: spec=%.1f small=%.1f large=%.1f" % (
-                v[16] / bins, v[17] / bins, v[18] / bins)
+            shares += " | wave-level Newton trips per step: spec=%.1f small=%.1f large=%.1f walk rounds=%.1f" % (
+                v[16] / bins, v[17] / bins, v[18] / bins, v[19] / bins)
             print("pen=%-18s wave%d cyc/step=%7.0f mean_int=%.2f | %s" % (
                 pens[p], w, tot / bins, r.total_intervals / (2.0 * bins), shares))
     pset.close()
