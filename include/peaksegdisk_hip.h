@@ -112,6 +112,16 @@ unsigned long long peakseg_hip_problem_set_bytes(psd_problem_set *set);
 
 void peakseg_hip_problem_set_destroy(psd_problem_set *set);
 
+/* Tests: parse a bedGraph file the way PeakSegFPOP_disk does (use_fast != 0: byte scanner with
+ * sscanf fallback; 0: the reference's sscanf format on every line) and return the status, the
+ * number of data lines and a hash of everything parsed. */
+int peakseg_hip_parse_probe(const char *path, int use_fast, int *n_lines,
+                            unsigned long long *hash);
+
+/* diagnostic builds (-DPSD_PROFILE): per-wave cycle counters of the forward kernel; -1 in
+ * normal builds */
+int peakseg_hip_problem_set_profile(psd_problem_set *set, int problem, long long *out);
+
 /* y[i] = exp(x[i]) (op 0) or log(x[i]) (op 1) evaluated on the device with the library's
  * deterministic math (include/peakseg_detmath.h); tests compare with the host build. */
 int peakseg_hip_math_probe(int op, int n, const double *x, double *y);

@@ -69,6 +69,11 @@ def declare(lib):
     lib.peakseg_hip_problem_set_bytes.restype = c.c_ulonglong
     lib.peakseg_hip_problem_set_destroy.argtypes = [c.c_void_p]
     lib.peakseg_hip_problem_set_destroy.restype = None
+    lib.peakseg_hip_parse_probe.argtypes = [c.c_char_p, c.c_int, c.POINTER(c.c_int),
+                                            c.POINTER(c.c_ulonglong)]
+    lib.peakseg_hip_parse_probe.restype = c.c_int
+    lib.peakseg_hip_problem_set_profile.argtypes = [c.c_void_p, c.c_int, c.c_void_p]
+    lib.peakseg_hip_problem_set_profile.restype = c.c_int
     lib.peakseg_hip_math_probe.argtypes = [c.c_int, c.c_int, c.c_void_p, c.c_void_p]
     lib.peakseg_hip_math_probe.restype = c.c_int
     return lib
@@ -80,7 +85,8 @@ EXPORTED_SYMBOLS = [
     "peakseg_hip_problem_set_create", "peakseg_hip_problem_set_solve",
     "peakseg_hip_problem_set_result", "peakseg_hip_problem_set_segments",
     "peakseg_hip_problem_set_export_db", "peakseg_hip_problem_set_bytes",
-    "peakseg_hip_problem_set_destroy", "peakseg_hip_math_probe",
+    "peakseg_hip_problem_set_destroy", "peakseg_hip_math_probe", "peakseg_hip_parse_probe",
+    "peakseg_hip_problem_set_profile",
 ]
 
 if not os.path.exists(LIB_PATH):

@@ -76,21 +76,88 @@ struct Coverage {
   int n() const { return (int)count.size(); }
 };
 
-/* Pass 1 of the reference: same sscanf format, same checks in the same order. */
-int read_bedGraph(const char *path, Coverage &cv) {
-  FILE *f = fopen(path, "r");
+/* One bedGraph line the way the reference's sscanf("%s %d %d %d%s") sees it
+ * (drv:175-178).  Returns the item count sscanf would return (-1 for an empty line). */
+static int scan_line_sscanf(const char *line, char *chrom, int *chromStart, int *chromEnd,
+                            int *coverage, char *extra) {
+  /* the reference reads "%s" into char[100] buffers (drv:166-167); bounded here */
+  return sscanf(line, "%99s %d %d %d%99s\n", chrom, chromStart, chromEnd, coverage, extra);
+}
+
+static inline bool is_ws(unsigned char c) {
+  return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r';
+}
+
+/* Fast path for the lines real files consist of: token, three decimal integers of at most
+ * nine digits (optional '-' / '+'), nothing else.  Returns false for anything it is not sure
+ * about; the caller then lets sscanf decide, so behaviour is the reference's by
+ * construction (tests/test_cabi_cpu.py fuzzes fast vs sscanf-only). */
+static bool scan_line_fast(const char *p, const char *end, char *chrom, int *v) {
+  while (p < end && is_ws((unsigned char)*p)) p++;
+  const char *tok = p;
+  while (p < end && !is_ws((unsigned char)*p)) p++;
+  size_t len = (size_t)(p - tok);
+  if (len == 0 || len > 99) return false;
+  memcpy(chrom, tok, len);
+  chrom[len] = 0;
+  for (int k = 0; k < 3; k++) {
+    const char *q = p;
+    while (p < end && is_ws((unsigned char)*p)) p++;
+    if (p == q) return false; /* the integer must be separated from the previous field */
+    bool neg = false;
+    if (p < end && (*p == '-' || *p == '+')) {
+      neg = *p == '-';
+      p++;
+    }
+    const char *d = p;
+    int x = 0;
+    while (p < end && *p >= '0' && *p <= '9') {
+      x = x * 10 + (*p - '0');
+      p++;
+    }
+    if (p == d || p - d > 9) return false;
+    v[k] = neg ? -x : x;
+  }
+  while (p < end && is_ws((unsigned char)*p)) p++;
+  return p == end; /* a fifth field: sscanf reports it */
+}
+
+/* Pass 1 of the reference (drv:173-205): same per-line conversions, same checks in the same
+ * order; the whole file is read once and shared by every penalty of a batch.
+ * use_fast = false forces the sscanf-only path (tests). */
+int read_bedGraph_impl(const char *path, Coverage &cv, bool use_fast) {
+  FILE *f = fopen(path, "rb");
   if (!f) return ERROR_UNABLE_TO_OPEN_BEDGRAPH;
-  char *line = nullptr;
-  size_t cap = 0;
-  int chromStart, chromEnd = 0, coverage, items, line_i = 0;
+  std::string buf;
+  {
+    char chunk[1 << 16];
+    size_t got;
+    while ((got = fread(chunk, 1, sizeof chunk, f)) > 0) buf.append(chunk, got);
+    fclose(f);
+  }
+  int chromStart = 0, chromEnd = 0, coverage = 0, items, line_i = 0;
   char chrom[100];
   char extra[100] = "";
   int prev_chromEnd = -1;
   int status = 0;
-  while (getline(&line, &cap, f) != -1) {
+  std::string tmp;
+  const char *p = buf.data(), *file_end = buf.data() + buf.size();
+  while (p < file_end) { /* std::getline: up to '\n', the last line may lack it */
+    const char *nl = (const char *)memchr(p, '\n', (size_t)(file_end - p));
+    const char *line_end = nl ? nl : file_end;
     line_i++;
-    /* the reference reads "%s" into char[100] buffers (drv:166-167,175-178); bounded here */
-    items = sscanf(line, "%99s %d %d %d%99s\n", chrom, &chromStart, &chromEnd, &coverage, extra);
+    int v[3];
+    if (use_fast && scan_line_fast(p, line_end, chrom, v)) {
+      chromStart = v[0];
+      chromEnd = v[1];
+      coverage = v[2];
+      items = 4;
+    } else {
+      tmp.assign(p, (size_t)(line_end - p));
+      /* an embedded NUL ends the line for sscanf, as line.c_str() does in the reference */
+      items = scan_line_sscanf(tmp.c_str(), chrom, &chromStart, &chromEnd, &coverage, extra);
+    }
+    p = nl ? nl + 1 : file_end;
     if (items < 4) {
       emit_text("problem: %d items on line %d\n", items, line_i);
       status = ERROR_NOT_ENOUGH_COLUMNS;
@@ -117,13 +184,13 @@ int read_bedGraph(const char *path, Coverage &cv) {
     cv.count.push_back(coverage);
     cv.weight.push_back(chromEnd - chromStart);
   }
-  free(line);
-  fclose(f);
   if (status) return status;
   if (line_i == 0) return ERROR_NO_DATA;
   cv.chrom = chrom;
   return 0;
 }
+
+int read_bedGraph(const char *path, Coverage &cv) { return read_bedGraph_impl(path, cv, true); }
 
 /* penalty string handling of drv:145-159 */
 int parse_penalty(const char *s, bool &is_Inf, double &penalty) {
@@ -534,6 +601,33 @@ extern "C" int peakseg_hip_problem_set_export_db(psd_problem_set *s, int p, cons
             fwrite(body.data(), 1, body.size(), f) == body.size();
   ok = fclose(f) == 0 && ok;
   return ok ? 0 : -1;
+}
+
+/* Tests: parse a bedGraph file with the fast path (use_fast != 0) or with sscanf only, and
+ * report the status, the line count and an FNV-1a hash of everything parsed. */
+extern "C" int peakseg_hip_parse_probe(const char *path, int use_fast, int *n_lines,
+                                       unsigned long long *hash) {
+  Coverage cv;
+  int st = read_bedGraph_impl(path, cv, use_fast != 0);
+  unsigned long long h = 1469598103934665603ull;
+  auto mix = [&h](const void *q, size_t n) {
+    const unsigned char *b = (const unsigned char *)q;
+    for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+  };
+  if (st == 0) {
+    mix(cv.chromEnd.data(), cv.chromEnd.size() * 4);
+    mix(cv.count.data(), cv.count.size() * 4);
+    mix(cv.weight.data(), cv.weight.size() * 4);
+    mix(cv.chrom.data(), cv.chrom.size());
+    mix(&cv.first_chromStart, 4);
+    mix(&cv.cum_weight, 8);
+    mix(&cv.cum_weighted_count, 8);
+    mix(&cv.min_log_mean, 8);
+    mix(&cv.max_log_mean, 8);
+  }
+  if (n_lines) *n_lines = cv.n();
+  if (hash) *hash = h;
+  return st;
 }
 
 /* diagnostic builds (-DPSD_PROFILE) only: per-wave cycle counters of the forward kernel */

@@ -155,3 +155,55 @@ def test_detmath_header_is_plain_c(tmp_path):
                    'double f(double x) { return psd_exp(x) + psd_log(x); }\n')
     subprocess.run(["gcc", "-std=gnu99", "-Wall", "-Werror", "-fsyntax-only", "-ffp-contract=off",
                     "-I" + os.path.join(ROOT, "include"), str(src)], check=True)
+
+
+def test_fast_parser_equals_sscanf(native, tmp_path):
+    """The byte-scanning bedGraph parser must behave exactly like the reference's
+    sscanf("%s %d %d %d%s") on every line: fuzz well-formed and malformed files and compare
+    status, line count and a hash of everything parsed with the sscanf-only path."""
+    import random
+    rng = random.Random(7)
+    lib = native.lib
+
+    def probe(path, fast):
+        n = ctypes.c_int()
+        h = ctypes.c_ulonglong()
+        st = lib.peakseg_hip_parse_probe(path.encode(), fast, ctypes.byref(n), ctypes.byref(h))
+        return st, n.value, h.value
+
+    def good_line(start, end, cnt, sep="\t"):
+        return "chr%d%s%d%s%d%s%d" % (rng.randrange(30), sep, start, sep, end, sep, cnt)
+
+    mutations = [
+        lambda s: s + " extra", lambda s: s + ".5", lambda s: s.replace("\t", "  \t "),
+        lambda s: "  " + s, lambda s: s + " \r", lambda s: s.rsplit("\t", 1)[0],
+        lambda s: "", lambda s: "   ", lambda s: s.replace("\t", ",", 1),
+        lambda s: s + "\t", lambda s: s.replace("\t", "\t+", 1),
+        lambda s: s.replace("\t", "\t-", 1), lambda s: s[:-1] + "x",
+        lambda s: "c" * 150 + s[4:], lambda s: s.rsplit("\t", 1)[0] + "\t12345678901",
+        lambda s: s.rsplit("\t", 1)[0] + "\t0x10", lambda s: s.replace("\t", "\v", 1),
+    ]
+    statuses = set()
+    for case in range(400):
+        lines = []
+        pos = rng.randrange(1000)
+        for _ in range(rng.randrange(1, 12)):
+            w = rng.randrange(1, 50)
+            lines.append(good_line(pos, pos + w, rng.randrange(0, 40),
+                                   sep=rng.choice(["\t", " ", "  ", "\t "])))
+            pos += w
+        if case % 3:
+            i = rng.randrange(len(lines))
+            lines[i] = rng.choice(mutations)(lines[i])
+        if rng.random() < 0.1:
+            lines[rng.randrange(len(lines))] = good_line(5, 3, 1)  # gap / reversed
+        text = "\n".join(lines) + ("\n" if rng.random() < 0.7 else "")
+        path = str(tmp_path / ("p%d.bedGraph" % case))
+        open(path, "w").write(text)
+        a, b = probe(path, 1), probe(path, 0)
+        assert a == b, (case, text, a, b)
+        statuses.add(a[0])
+    assert {0, 4, 5, 6} <= statuses
+    open(str(tmp_path / "empty"), "w").write("")
+    assert probe(str(tmp_path / "empty"), 1) == probe(str(tmp_path / "empty"), 0)
+    assert probe(str(tmp_path / "empty"), 1)[0] == 9
