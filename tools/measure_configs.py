@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Measure the other BASELINE.json configurations on one MI355X (they are parity-test cases,
+not bench lines; these numbers go into DESIGN.md / profiles/):
+
+  c4   24 contigs x 64 penalties (configs[3]) scaled to one GPU: contig lengths log-uniform in
+       [1e4, 1e6] instead of [1e5, 1e7] so that the store fits one device; 1536 problems in one
+       launch -- the regime where the chip is actually filled
+  c5   adversarial increasing counts (configs[4], vignettes/Worst_case.Rmd) at penalty 100:
+       lists far beyond LDS -> HBM spill path
+  c3   sequentialSearch_dir (configs[2]) on one synthetic contig through the file-level API
+
+usage: python tools/measure_configs.py c4|c5|c3 [size]
+"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def c4(scale_hi=1e6):
+    from peaksegdisk_amd import synthetic
+    from peaksegdisk_amd.parallel import solve_grid
+    rng = np.random.default_rng(4)
+    lens = np.exp(rng.uniform(np.log(scale_hi / 100), np.log(scale_hi), 24)).astype(int)
+    contigs = []
+    for k, n in enumerate(lens):
+        cs, ce, cnt = synthetic.poisson_coverage(int(n), seed=100 + k)
+        contigs.append((cnt, (ce - cs).astype(np.int32)))
+    pens = [float(p) for p in synthetic.penalty_grid(64)]
+    t0 = time.time()
+    out = solve_grid(contigs, pens, None, 0)
+    wall = time.time() - t0
+    bins = int(lens.sum()) * 64
+    peaks = sum(int((v["summary"][0] - 1) // 2) for v in out.values())
+    return {"config": "c4-scaled", "contigs": 24, "penalties": 64, "problems": len(out),
+            "contig_bins_min": int(lens.min()), "contig_bins_max": int(lens.max()),
+            "bin_penalty_pairs": bins, "wall_s_incl_upload_and_download": wall,
+            "bins_per_s": bins / wall, "total_peaks": peaks}
+
+
+def c5(n=100000):
+    from peaksegdisk_amd import ProblemSet, synthetic
+    cs, ce, cnt = synthetic.increasing_coverage(n)
+    pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, 100.0)])
+    f_ms, b_ms = pset.solve()
+    r = pset.result(0)
+    out = {"config": "c5", "bins": n, "penalty": 100, "forward_ms": f_ms, "backtrack_ms": b_ms,
+           "status": r.status, "segments": r.n_segments, "max_intervals": r.max_intervals,
+           "mean_intervals": r.total_intervals / (2.0 * n), "spill_steps": r.spill_steps,
+           "bins_per_s": n / ((f_ms + b_ms) / 1e3), "hbm_bytes": pset.hbm_bytes}
+    pset.close()
+    return out
+
+
+def c3(n=2000000, peaks=300):
+    import peaksegdisk_amd as psd
+    from peaksegdisk_amd import synthetic
+    cs, ce, cnt = synthetic.poisson_coverage(n, seed=3)
+    d = tempfile.mkdtemp(prefix="psd_c3_")
+    pdir = os.path.join(d, "chrSynth-0-%d" % int(ce[-1]))
+    os.makedirs(pdir)
+    synthetic.write_bedgraph(os.path.join(pdir, "coverage.bedGraph"), cs, ce, cnt)
+    t0 = time.time()
+    fit = psd.sequentialSearch_dir(pdir, peaks)
+    wall = time.time() - t0
+    others = fit.others
+    return {"config": "c3", "bins": n, "target_peaks": peaks,
+            "found_peaks": int(fit.loss["peaks"].iloc[0]), "dp_runs": int(len(others)),
+            "penalties": [float(x) for x in others["penalty"]],
+            "peaks_by_run": [int(x) for x in others["peaks"]],
+            "seconds_by_run": [float(x) for x in others["seconds"]], "wall_s": wall,
+            "bins_per_s_over_all_runs": n * len(others) / wall}
+
+
+if __name__ == "__main__":
+    which = sys.argv[1]
+    arg = [float(a) for a in sys.argv[2:]]
+    fn = {"c4": c4, "c5": c5, "c3": c3}[which]
+    res = fn(*[int(a) if which != "c4" else a for a in arg])
+    print(json.dumps(res))
