@@ -274,7 +274,7 @@ PSD_D void copy_list_across(const LS &src, int n, const LD &dst) {
  *   (t == 1: up_1 = the min-less result, down_1 = down_0)
  * then multiply, add the data point, multiply (drv:316-321,365-370).
  * Returns the new piece count or -(WERR_* bits). */
-template <class L, class S>
+template <bool HELP, class L, class S>
 PSD_D int chain_step(const DeviceArgs &a, ArenaCursor &cur, unsigned long long fn_index,
                      int chain, int t, const L &other_prev, int n_other, const L &own_prev,
                      int n_own, const L &own_new, const L &mlist, const S &sc, int cap,
@@ -299,7 +299,7 @@ PSD_D int chain_step(const DeviceArgs &a, ArenaCursor &cur, unsigned long long f
     }
   } else {
     const L f1 = chain == 0 ? mlist : mlist.shifted(cap - nm);
-    n_new = uniform_i(min_env_wave(f1, nm, own_prev, n_own, own_new, cap, sc));
+    n_new = uniform_i(min_env_wave<HELP>(f1, nm, own_prev, n_own, own_new, cap, sc, chain));
   }
   if (n_new < 0) return n_new;
   PSD_PROF_T0();
@@ -316,9 +316,26 @@ PSD_D int chain_step(const DeviceArgs &a, ArenaCursor &cur, unsigned long long f
  * every function has at most LDS_CAP pieces; when an operation overflows, the step is redone
  * with all lists in the HBM spill area, and the problem returns to LDS once both functions
  * have shrunk below LDS_CAP/2. */
-__global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
+#ifdef PSD_HELPER_WAVES
+constexpr bool USE_HELPER = true;
+constexpr int FORWARD_THREADS = 256; /* waves 0,1: the two chains; waves 2,3: their helpers */
+/* every workgroup barrier of a main wave is mirrored by its helper */
+PSD_D void block_sync(int chain) {
+  if (!mail_wait(chain)) {
+    if (lane_id() == 0) g_sm.mail[chain].abort = 1;
+  }
+  mail_post(chain, HOP_BARRIER);
+  __syncthreads();
+}
+#else
+constexpr bool USE_HELPER = false;
+constexpr int FORWARD_THREADS = 128;
+PSD_D void block_sync(int) { __syncthreads(); }
+#endif
+
+__global__ __launch_bounds__(FORWARD_THREADS) void fpop_forward_kernel(DeviceArgs a) {
   const int p = (int)blockIdx.x;
-  const int chain = uniform_i(wave_id()); /* uniform per wave: say so (scalar branches) */
+  const int chain = uniform_i(wave_id()) & 1; /* uniform per wave: say so (scalar branches) */
   const int lane = lane_id();
   const int contig = a.prob_contig[p];
   const int N = a.contig_n[contig];
@@ -338,10 +355,24 @@ __global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
     for (int i = 0; i < 6; i++) g_sm.n[i] = 0;
     g_sm.serial[0] = g_sm.serial[1] = 0;
 #ifdef PSD_PROFILE
-    for (int i = 0; i < N_PROF; i++) g_sm.prof[0][i] = g_sm.prof[1][i] = 0;
+    for (int i = 0; i < N_PROF; i++)
+      g_sm.prof[0][i] = g_sm.prof[1][i] = g_sm.prof[2][i] = g_sm.prof[3][i] = 0;
+#endif
+#ifdef PSD_HELPER_WAVES
+    for (int c = 0; c < 2; c++) {
+      g_sm.mail[c].seq_cmd = g_sm.mail[c].seq_done = 0;
+      g_sm.mail[c].op = 0;
+      g_sm.mail[c].abort = 0;
+    }
 #endif
   }
   __syncthreads();
+#ifdef PSD_HELPER_WAVES
+  if (wave_id() >= 2) {
+    helper_loop(chain);
+    return;
+  }
+#endif
 
   ArenaCursor cur;
   cur.base = 0;
@@ -379,7 +410,7 @@ __global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
     if (in_hbm && n_own <= LDS_CAP / 2 && n_other <= LDS_CAP / 2) {
       copy_list_across(global_list(a, p, id_own_prev), n_own, lds_list(id_own_prev));
       in_hbm = false;
-      __syncthreads();
+      block_sync(chain);
     }
     int n_new = 0;
     for (;;) { /* at most two passes: LDS, then HBM after an overflow */
@@ -397,13 +428,13 @@ __global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
           n_new = 1;
         }
       } else if (!in_hbm) {
-        n_new = chain_step(a, cur, fn0 + (unsigned long long)t, chain, t,
+        n_new = chain_step<USE_HELPER>(a, cur, fn0 + (unsigned long long)t, chain, t,
                            lds_list(id_other_prev), n_other, lds_list(id_own_prev),
                            n_own, lds_list(id_own_new), mlist, lsc, LDS_CAP,
                            penalty / cum_weight_prev_i, cum_weight_prev_i, w, coverage,
                            cum_weight_new);
       } else {
-        n_new = chain_step(a, cur, fn0 + (unsigned long long)t, chain, t,
+        n_new = chain_step<false>(a, cur, fn0 + (unsigned long long)t, chain, t,
                            global_list(a, p, id_other_prev), n_other,
                            global_list(a, p, id_own_prev), n_own, global_list(a, p, id_own_new),
                            global_list(a, p, 4 + chain), global_scratch(a, p, chain),
@@ -426,7 +457,7 @@ __global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
           g_sm.abort_status[slot] = PST_ARENA_FULL;
       }
       PSD_PROF_ADD(PROF_ARENA);
-      __syncthreads();
+      block_sync(chain);
       PSD_PROF_ADD(PROF_BARRIER);
       status = uniform_i(g_sm.abort_status[slot]);
       /* three rotating slots: the one cleared here is first written two barriers later */
@@ -437,7 +468,7 @@ __global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
         copy_list_across(lds_list(id_own_prev), n_own, global_list(a, p, id_own_prev));
         in_hbm = true;
         status = 0;
-        __syncthreads();
+        block_sync(chain);
         continue;
       }
       break;
@@ -455,7 +486,11 @@ __global__ __launch_bounds__(128) void fpop_forward_kernel(DeviceArgs a) {
     g_sm.total_up = total_intervals;
     g_sm.max_up = max_intervals;
   }
-  __syncthreads();
+  block_sync(chain);
+#ifdef PSD_HELPER_WAVES
+  if (mail_wait(chain)) mail_post(chain, HOP_EXIT);
+  else if (lane == 0) g_sm.mail[chain].abort = 1;
+#endif
 #ifdef PSD_PROFILE
   if (lane == 0 && a.prof) {
     long long *dst = a.prof + ((long long)p * 2 + chain) * N_PROF;

@@ -53,7 +53,24 @@ struct ScratchStore {
   int cls[LDS_CAP];
   int iv[2 * LDS_CAP];
 };
-constexpr int N_PROF = 20;
+#if !defined(PSD_NO_HELPER_WAVES) && !defined(PSD_HELPER_WAVES)
+#define PSD_HELPER_WAVES 1 /* the shipped configuration; -DPSD_NO_HELPER_WAVES for A/B runs */
+#endif
+/* Helper waves (PSD_HELPER_WAVES): every chain's main wave has a second wave that evaluates
+ * independent parts of the envelope classification concurrently -- the mean-space midpoint
+ * cost while the main wave computes the optimum of the difference piece, and the larger-root
+ * Newton solves while the main wave does the smaller-root ones.  Lane k of the helper works
+ * on lane k's interval; arguments and results cross through this LDS mailbox. */
+enum { HOP_BARRIER = 1, HOP_EXIT = 2, HOP_MID = 3, HOP_LARGE = 4 };
+struct Mail {
+  int seq_cmd, seq_done, op, abort;
+  int flags[64];
+  double d_lin[64], d_log[64], d_con[64], ea[64], eb[64]; /* HOP_MID (and kept for HOP_LARGE) */
+  double om[64], oc2[64], b[64], cr[64];                  /* HOP_LARGE */
+  double res_mid[64], res_large[64];
+};
+
+constexpr int N_PROF = 24;
 /* the workgroup's LDS: lists 0,1 = up (double-buffered), 2,3 = down, 4,5 = per-wave
  * min-less / min-more result */
 struct SharedBlock {
@@ -65,22 +82,65 @@ struct SharedBlock {
   unsigned long long total_up;
   int max_up;
   int serial[2];
+#ifdef PSD_HELPER_WAVES
+  Mail mail[2];
+#endif
 #ifdef PSD_PROFILE
-  long long prof[2][N_PROF];
+  long long prof[4][N_PROF];
 #endif
 };
 
 PSD_LDS SharedBlock g_sm;
 
+#ifdef PSD_HELPER_WAVES
+constexpr int MAIL_SPIN_LIMIT = 1 << 26;
+/* main wave: wait until the helper has finished the last posted command */
+PSD_D bool mail_wait(int chain) {
+  Mail &m = g_sm.mail[chain];
+  const int want = flag_load(&m.seq_cmd);
+  for (int spin = 0; spin < MAIL_SPIN_LIMIT; spin++) {
+    if (flag_load(&m.seq_done) == want) return true;
+    spin_pause();
+  }
+  return false;
+}
+/* main wave: hand the next command over (arguments already written by the lanes) */
+PSD_D void mail_post(int chain, int op) {
+  Mail &m = g_sm.mail[chain];
+  wave_sync();
+  if (lane_id() == 0) {
+    m.op = op;
+    flag_store(&m.seq_cmd, flag_load(&m.seq_cmd) + 1);
+  }
+  wave_sync(); /* no lane reads seq_cmd (mail_wait) before lane 0 has advanced it */
+}
+#endif
+
 #ifdef PSD_PROFILE
-#define PSD_PROF_T0() long long prof_t0_ = cycle_now()
+#define PSD_PROF_T0()                \
+  long long prof_t0_ = cycle_now(); \
+  long long prof_sub_ = prof_t0_;   \
+  (void)prof_sub_
 #define PSD_PROF_ADD(slot)                                             \
   do {                                                                 \
     long long now_ = cycle_now();                                      \
     if (lane_id() == 0) g_sm.prof[wave_id()][slot] += now_ - prof_t0_; \
     prof_t0_ = now_;                                                   \
   } while (0)
+#define PSD_PROF_SUB0() prof_sub_ = cycle_now()
+#define PSD_PROF_SUB(slot)                                              \
+  do {                                                                  \
+    long long now_ = cycle_now();                                       \
+    if (lane_id() == 0) g_sm.prof[wave_id()][slot] += now_ - prof_sub_; \
+    prof_sub_ = now_;                                                   \
+  } while (0)
 #else
+#define PSD_PROF_SUB0() \
+  do {                  \
+  } while (0)
+#define PSD_PROF_SUB(slot) \
+  do {                     \
+  } while (0)
 #define PSD_PROF_T0() \
   do {                \
   } while (0)
@@ -94,7 +154,8 @@ enum {
   PROF_C_LOAD = 10, PROF_C_MID = 11, PROF_C_OPT = 12, PROF_C_SMALL = 13, PROF_C_LARGE = 14,
   PROF_C_TAIL = 15,
   PROF_IT_SPEC = 16, PROF_IT_SMALL = 17, PROF_IT_LARGE = 18, /* wave-level Newton trip counts */
-  PROF_IT_ROUNDS = 19 /* walk state-machine rounds */
+  PROF_IT_ROUNDS = 19, /* walk state-machine rounds */
+  PROF_S_ASSIGN = 20, PROF_S_LOAD = 21, PROF_S_NEWTON = 22 /* inside the speculation round */
 };
 #ifdef PSD_PROFILE
 #define PSD_PROF_ITERS(slot, steps)                                 \
@@ -271,6 +332,7 @@ enum {
   WERR_SENTINEL = 4,      /* push_min_pieces neighbour outside the list */
   WERR_ZERO_INTERVAL = 8, /* fpl:933 zero-size merged interval */
   WERR_ARENA = 16,        /* the in-HBM store is full */
+  WERR_HELPER = 32,       /* a helper wave did not answer (never expected) */
 };
 
 /* A lane's own copy of piece `lane` and of what the first pass computed for it (functions of
@@ -696,6 +758,7 @@ PSD_NOINLINE int min_more_wave(L in_, int n_, L out_, int cap_, S s_, int data_i
   unsigned long long sp_ev = 0, sp_inside = 0;
   double sp_mu = PSD_INF;
   int my_base = 0;
+  PSD_PROF_SUB0();
   if (small) {
     unsigned long long m_start = ballot(lane < n && P.cls != CLS_STORE);
     int total = 0;
@@ -718,20 +781,35 @@ PSD_NOINLINE int min_more_wave(L in_, int n_, L out_, int cap_, S s_, int data_i
       }
       bool inside = false, at_left = false;
       int sp_steps = 0;
+      PSD_PROF_SUB(PROF_S_ASSIGN);
+      double level = 0.0, t_mx = 0.0, t_rc = 0.0, t_mn = 0.0, t_lc = 0.0;
+      Coef c = {0.0, 0.0, 0.0};
+      PieceOpt o = {0.0, 0.0, 0.0, 0.0};
       if (tj >= 0) {
-        double level = (s.cls(tj) == CLS_CONST_MU) ? s.muc(tj) : s.rc(tj);
-        Coef c = load_coef(in, tk);
+        level = (s.cls(tj) == CLS_CONST_MU) ? s.muc(tj) : s.rc(tj);
+        c = load_coef(in, tk);
+        o.mean = s.om(tk);
+        o.log_mean = s.mu(tk);
+        o.cost = s.muc(tk);
+        o.cost2 = s.oc2(tk);
+        t_mx = in.mx(tk);
+        t_rc = s.rc(tk);
+        t_mn = in.mn(tk);
+        t_lc = s.lc(tk);
+      }
+      PSD_PROF_SUB(PROF_S_LOAD);
+      if (tj >= 0) {
         if (c.Log == 0) {
           sp_mu = d_log((level - c.Constant) / c.Linear); /* fpl:563 */
         } else {
-          PieceOpt o = {s.om(tk), s.mu(tk), s.muc(tk), s.oc2(tk)};
           if (has_two_roots(c, o, level)) {
-            sp_mu = get_larger_root(c, o, in.mx(tk), s.rc(tk), level, &sp_steps);
+            sp_mu = get_larger_root(c, o, t_mx, t_rc, level, &sp_steps);
           }
         }
-        inside = in.mn(tk) < sp_mu && sp_mu < in.mx(tk);
-        if (!inside) at_left = s.lc(tk) <= level + NEWTON_EPSILON;
+        inside = t_mn < sp_mu && sp_mu < t_mx;
+        if (!inside) at_left = t_lc <= level + NEWTON_EPSILON;
       }
+      PSD_PROF_SUB(PROF_S_NEWTON);
       PSD_PROF_ITERS(PROF_IT_SPEC, sp_steps);
       sp_ev = ballot(inside || at_left);
       sp_inside = ballot(inside);
@@ -1188,8 +1266,10 @@ PSD_D void env_interval_at(const L &f1, int n1, const L &f2, int n2, int i1, int
  * the same time (predicated phases) instead of each lane walking its own branch of
  * push_min_pieces -- a wave otherwise executes the union of all branches one after another.
  * The arithmetic per lane is identical to env_interval(). */
+template <bool HELP>
 PSD_D void env_classify_lanes(bool valid, const Coef &c1, const Coef &c2, double a, double b,
-                              bool same_at_left, bool same_at_right, Cands &out) {
+                              bool same_at_left, bool same_at_right, Cands &out, int chain,
+                              int &err) {
   out.n = 0;
   out.first = 0;
   out.x1 = out.x2 = 0.0;
@@ -1205,7 +1285,26 @@ PSD_D void env_classify_lanes(bool valid, const Coef &c1, const Coef &c2, double
   if (act) {
     ea = d_exp(a);
     eb = d_exp(b);
-    cost_diff_mid = get_cost(d, d_log((eb + ea) / 2));
+  }
+  bool mid_posted = false;
+#ifdef PSD_HELPER_WAVES
+  if (HELP) {
+    if (ballot(act)) { /* the helper evaluates the midpoint cost meanwhile */
+      Mail &m = g_sm.mail[chain];
+      const int l = lane_id();
+      m.flags[l] = act ? 1 : 0;
+      m.d_lin[l] = d.Linear;
+      m.d_log[l] = d.Log;
+      m.d_con[l] = d.Constant;
+      m.ea[l] = ea;
+      m.eb[l] = eb;
+      mail_post(chain, HOP_MID);
+      mid_posted = true;
+    }
+  } else
+#endif
+  {
+    if (act) cost_diff_mid = get_cost(d, d_log((eb + ea) / 2));
   }
   PSD_PROF_ADD(PROF_C_MID);
   const bool both = same_at_left && same_at_right;
@@ -1235,9 +1334,41 @@ PSD_D void env_classify_lanes(bool valid, const Coef &c1, const Coef &c2, double
   /* phases E, F: the two Newton solves (fpl:1023-1028) */
   double smaller_log_mean = PSD_INF, larger_log_mean = PSD_INF;
   int it_small = 0, it_large = 0;
+  bool large_posted = false;
+#ifdef PSD_HELPER_WAVES
+  if (HELP) {
+    Mail &m = g_sm.mail[chain];
+    const int l = lane_id();
+    if (mid_posted) {
+      if (!mail_wait(chain)) err |= WERR_HELPER;
+      cost_diff_mid = m.res_mid[l];
+    }
+    if (ballot(two_roots)) { /* larger roots on the helper, smaller roots here */
+      m.flags[l] = two_roots ? 2 : 0;
+      m.om[l] = o.mean;
+      m.oc2[l] = o.cost2;
+      m.b[l] = b;
+      m.cr[l] = cost_diff_right;
+      mail_post(chain, HOP_LARGE);
+      large_posted = true;
+    }
+  }
+#endif
   if (two_roots) smaller_log_mean = get_smaller_root(d, o, a, cost_diff_left, 0.0, &it_small);
   PSD_PROF_ADD(PROF_C_SMALL);
-  if (two_roots) larger_log_mean = get_larger_root(d, o, b, cost_diff_right, 0.0, &it_large);
+#ifdef PSD_HELPER_WAVES
+  if (HELP) {
+    if (large_posted) {
+      if (!mail_wait(chain)) err |= WERR_HELPER;
+      larger_log_mean = g_sm.mail[chain].res_large[lane_id()];
+    }
+  } else
+#endif
+  {
+    if (two_roots) larger_log_mean = get_larger_root(d, o, b, cost_diff_right, 0.0, &it_large);
+  }
+  (void)large_posted;
+  (void)mid_posted;
   PSD_PROF_ADD(PROF_C_LARGE);
   PSD_PROF_ITERS(PROF_IT_SMALL, it_small);
   PSD_PROF_ITERS(PROF_IT_LARGE, it_large);
@@ -1402,6 +1533,43 @@ PSD_D bool bit_identical(const Coef &last, double last_prv, int last_di, const C
          last_di == di;
 }
 
+#ifdef PSD_HELPER_WAVES
+/* Body of a helper wave: serve the main wave of `chain` until HOP_EXIT. */
+PSD_D void helper_loop(int chain) {
+  Mail &m = g_sm.mail[chain];
+  const int lane = lane_id();
+  int seen = 0;
+  for (;;) {
+    int cmd = seen;
+    for (int spin = 0;; spin++) {
+      cmd = flag_load(&m.seq_cmd);
+      if (cmd != seen) break;
+      if (spin > MAIL_SPIN_LIMIT || flag_load(&m.abort)) return;
+      spin_pause();
+    }
+    seen = cmd;
+    const int op = uniform_i(m.op);
+    if (op == HOP_EXIT) return;
+    if (op == HOP_BARRIER) {
+      __syncthreads();
+    } else if (op == HOP_MID) {
+      if (m.flags[lane] & 1) {
+        Coef d = {m.d_lin[lane], m.d_log[lane], m.d_con[lane]};
+        m.res_mid[lane] = get_cost(d, d_log((m.eb[lane] + m.ea[lane]) / 2)); /* fpl:960-961 */
+      }
+    } else if (op == HOP_LARGE) {
+      if (m.flags[lane] & 2) {
+        Coef d = {m.d_lin[lane], m.d_log[lane], m.d_con[lane]};
+        PieceOpt o = {m.om[lane], 0.0, 0.0, m.oc2[lane]};
+        m.res_large[lane] = get_larger_root(d, o, m.b[lane], m.cr[lane], 0.0);
+      }
+    }
+    wave_sync();
+    if (lane == 0) flag_store(&m.seq_done, seen);
+  }
+}
+#endif
+
 /* exact sequential replay of fpl:832-860 + push_piece on lane 0 (cold path) */
 template <class L, class S>
 PSD_NOINLINE int min_env_serial(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, int K_) {
@@ -1447,8 +1615,9 @@ PSD_NOINLINE int min_env_serial(L f1_, int n1_, L f2_, int n2_, L out_, int cap_
 }
 
 /* min-envelope: out = pointwise min(f1, f2). */
-template <class L, class S>
-PSD_NOINLINE int min_env_wave(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_) {
+template <bool HELP, class L, class S>
+PSD_NOINLINE int min_env_wave(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, int chain_) {
+  const int chain = uniform_i(chain_);
   const L f1 = f1_.uniformed(), f2 = f2_.uniformed(), out = out_.uniformed();
   const S s = s_.uniformed();
   const int n1 = uniform_i(n1_), n2 = uniform_i(n2_), cap = uniform_i(cap_);
@@ -1568,7 +1737,7 @@ PSD_NOINLINE int min_env_wave(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, 
     }
     env_neighbour_flags(f1, f2, s, k, K, valid, valid && same_funs(c1, c2), sl, sr);
     PSD_PROF_ADD(PROF_C_LOAD);
-    env_classify_lanes(valid && err == 0, c1, c2, ia, ib, sl, sr, cd);
+    env_classify_lanes<HELP>(valid && err == 0, c1, c2, ia, ib, sl, sr, cd, chain, err);
     PSD_PROF_ADD(PROF_CLASSIFY);
     /* first / last candidate of this lane */
     const int src0 = cd.first, src1 = cd.first ^ 1; /* the third piece has source src0 again */

@@ -457,7 +457,8 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
   for (int attempt = 0;; attempt++) {
     HIP_TRY(hipMemsetAsync(s->d.ar_next_chunk, 0, sizeof(unsigned long long), s->stream));
     HIP_TRY(hipEventRecord(s->ev[0], s->stream));
-    hipLaunchKernelGGL(psd::fpop_forward_kernel, dim3((unsigned)s->n_problems), dim3(128), 0,
+    hipLaunchKernelGGL(psd::fpop_forward_kernel, dim3((unsigned)s->n_problems),
+                       dim3(psd::FORWARD_THREADS), 0,
                        s->stream, s->d);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[1], s->stream));

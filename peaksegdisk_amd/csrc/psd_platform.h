@@ -94,6 +94,21 @@ PSD_D long long cycle_now() { return 0; }
 PSD_D long long cycle_now() { return (long long)__builtin_readcyclecounter(); }
 #endif
 
+/* flag hand-off between two waves of a workgroup through LDS */
+#ifdef PSD_EMU
+PSD_D int flag_load(const int *p) { return *(const volatile int *)p; }
+PSD_D void flag_store(int *p, int v) { *(volatile int *)p = v; }
+PSD_D void spin_pause() { emu::yield_fiber(); }
+#else
+PSD_D int flag_load(const int *p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+PSD_D void flag_store(int *p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+PSD_D void spin_pause() { __builtin_amdgcn_s_sleep(1); }
+#endif
+
 template <class T>
 PSD_D T *uniform_p(T *p) {
 #ifdef PSD_EMU

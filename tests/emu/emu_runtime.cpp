@@ -155,6 +155,8 @@ int shfl_i32(int v, int src) {
 
 void wave_sync() { (void)collective(0); }
 
+void yield_fiber() { yield_to_scheduler(); }
+
 void syncthreads() {
   BlockState *b = g_blk;
   int mygen = b->bar_gen;
@@ -193,6 +195,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
     blk.live = (int)nthreads;
     blk.bar_arrived = 0;
     blk.bar_gen = 0;
+    int idle_rounds = 0; /* spin-wait loops (yield_fiber) may legitimately idle a few rounds */
     while (blk.live > 0) {
       blk.progress = false;
       for (unsigned t = 0; t < nthreads; t++) {
@@ -202,7 +205,8 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
         g_cur = &f.ctx;
         psd_emu_switch(&blk.sched_sp, f.sp);
       }
-      if (!blk.progress && blk.live > 0) {
+      if (blk.progress) idle_rounds = 0;
+      if (!blk.progress && blk.live > 0 && ++idle_rounds > 64) {
         fprintf(stderr,
                 "hip_emu: deadlock in block %u (lanes disagree on a collective or barrier)\n", b);
         abort();

@@ -47,6 +47,7 @@ double shfl_f64(double v, int src);
 int shfl_i32(int v, int src);
 void wave_sync();
 void syncthreads();
+void yield_fiber(); /* let the other fibers run (spin-wait loops) */
 void launch(dim3 grid, dim3 block, const std::function<void()> &body);
 }  // namespace emu
 

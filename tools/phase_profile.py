@@ -17,8 +17,8 @@ sys.path.insert(0, ROOT)
 NAMES = ["pre(costs+classes)", "walk(state machine+roots)", "env table", "env classify",
          "env compact", "scale_add", "arena", "barrier wait", "env serial", "TOTAL",
          "c.load", "c.mid", "c.opt", "c.small", "c.large", "c.tail",
-         "it.spec", "it.small", "it.large", "-"]
-NP = 20
+         "it.spec", "it.small", "it.large", "-", "s.assign", "s.load", "s.newton", "-"]
+NP = 24
 
 
 def main():
@@ -51,7 +51,7 @@ def main():
             v = buf[w * NP:(w + 1) * NP]
             tot = float(v[9])
             shares = " ".join("%s=%.1f%%" % (NAMES[i].split("(")[0], 100.0 * v[i] / tot)
-                              for i in list(range(9)) + list(range(10, 16)))
+                              for i in list(range(9)) + list(range(10, 16)) + [20, 21, 22])
             shares += " | wave-level Newton trips per step: spec=%.1f small=%.1f large=%.1f walk rounds=%.1f" % (
                 v[16] / bins, v[17] / bins, v[18] / bins, v[19] / bins)
             print("pen=%-18s wave%d cyc/step=%7.0f mean_int=%.2f | %s" % (
