@@ -67,6 +67,8 @@ def declare(lib):
     lib.peakseg_hip_problem_set_export_db.restype = c.c_int
     lib.peakseg_hip_problem_set_bytes.argtypes = [c.c_void_p]
     lib.peakseg_hip_problem_set_bytes.restype = c.c_ulonglong
+    lib.peakseg_hip_problem_set_kernel_build.argtypes = [c.c_void_p]
+    lib.peakseg_hip_problem_set_kernel_build.restype = c.c_char_p
     lib.peakseg_hip_problem_set_destroy.argtypes = [c.c_void_p]
     lib.peakseg_hip_problem_set_destroy.restype = None
     lib.peakseg_hip_parse_probe.argtypes = [c.c_char_p, c.c_int, c.POINTER(c.c_int),
@@ -86,7 +88,7 @@ EXPORTED_SYMBOLS = [
     "peakseg_hip_problem_set_result", "peakseg_hip_problem_set_segments",
     "peakseg_hip_problem_set_export_db", "peakseg_hip_problem_set_bytes",
     "peakseg_hip_problem_set_destroy", "peakseg_hip_math_probe", "peakseg_hip_parse_probe",
-    "peakseg_hip_problem_set_profile",
+    "peakseg_hip_problem_set_profile", "peakseg_hip_problem_set_kernel_build",
 ]
 
 if not os.path.exists(LIB_PATH):

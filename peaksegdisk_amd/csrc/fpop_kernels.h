@@ -14,10 +14,9 @@
  *   math_probe_kernel     element-wise psd_exp / psd_log (tests: host == device bit for bit).
  *
  * Included by peakseg_hip.cpp (hipcc, gfx950) and by tests/emu (g++ + hip_emu.h).
- */
-#ifndef PSD_FPOP_KERNELS_H
-#define PSD_FPOP_KERNELS_H
-
+ *
+ * NO include guard: peakseg_hip.cpp includes this file once per build variant (PSD_VARIANT =
+ * namespace name, PSD_LDS_CAP, PSD_HELPER_WAVES), see fpop_wave.h. */
 #include "fpop_wave.h"
 
 #if defined(__clang__)
@@ -25,68 +24,7 @@
 #endif
 
 namespace psd {
-
-constexpr int ARENA_CHUNK_LOG2 = 16;  /* arena is handed out in chunks of 65536 pieces */
-constexpr int ARENA_CHUNK = 1 << ARENA_CHUNK_LOG2;
-constexpr int FN_COUNT_BITS = 24;     /* fn_ref = (arena offset << 24) | piece count */
-
-/* problem status written by the kernels (0 = ok) */
-enum {
-  PST_OK = 0,
-  PST_LDS_OVERFLOW = 1,  /* a list outgrew LDS_CAP and the spill path is not available */
-  PST_ARENA_FULL = 2,    /* host retries with a larger arena */
-  PST_REF_THROW = 3,     /* the reference would throw / loop / read a list sentinel */
-  PST_BACKTRACK = 4,     /* findMean found no piece (the reference would never return) */
-};
-
-struct ProbResult {
-  double best_cost;       /* Minimize() of the last down function (drv:404-406) */
-  double best_log_mean;
-  double prev_log_mean;
-  int prev_seg_end;
-  int status;
-  int wave_err;           /* WERR_* bits for diagnostics */
-  int max_intervals;      /* drv:374-379 */
-  unsigned long long total_intervals; /* drv:373 */
-  int n_segments;         /* filled by the backtrack kernel */
-  int n_equality;         /* drv:411,436 */
-  int n_serial_env;       /* min-envelope calls that needed the sequential replay */
-  int step_reached;
-  int spill_steps;        /* data points processed with the lists in the HBM spill area */
-};
-
-struct DeviceArgs {
-  int n_problems;
-  /* per problem */
-  const int *prob_contig;
-  const double *prob_penalty;
-  const long long *prob_fn_off;  /* into fn_ref: 2*N entries (up: [0,N), down: [N,2N)) */
-  const long long *prob_seg_off; /* into seg_start / seg_mean: N+1 entries */
-  ProbResult *result;
-  /* per contig */
-  const int *contig_n;
-  const long long *contig_off; /* into count / weight */
-  const double *contig_min_log_mean;
-  const double *contig_max_log_mean;
-  const int *count;  /* 4th bedGraph column */
-  const int *weight; /* chromEnd - chromStart */
-  /* arena: the in-HBM cost-function store */
-  double *ar_mx;
-  double *ar_prv;
-  int *ar_di;
-  unsigned long long ar_cap; /* pieces */
-  unsigned long long *ar_next_chunk;
-  unsigned long long *fn_ref;
-  /* segment tables, in backtrack order */
-  int *seg_start;   /* data index whose chromEnd starts the segment; -1 = first_chromStart */
-  double *seg_mean; /* exp(best_log_mean) */
-  long long *prof;  /* PSD_PROFILE builds: per (problem, wave) cycle counters, else NULL */
-  /* spill area for functions with more than LDS_CAP pieces: per problem 48*spill_cap doubles
-   * (6 lists x 6 fields + 2 waves x 6 scratch arrays) and 12*spill_cap ints */
-  double *spill_f64;
-  int *spill_i32;
-  int spill_cap;
-};
+namespace PSD_VARIANT {
 
 PSD_D GlobalList global_list(const DeviceArgs &a, int p, int id) {
   const size_t cap = (size_t)a.spill_cap;
@@ -333,8 +271,8 @@ constexpr int FORWARD_THREADS = 128;
 PSD_D void block_sync(int) { __syncthreads(); }
 #endif
 
-__global__ __launch_bounds__(FORWARD_THREADS) void fpop_forward_kernel(DeviceArgs a) {
-  const int p = (int)blockIdx.x;
+__global__ __launch_bounds__(FORWARD_THREADS) PSD_OCC void fpop_forward_kernel(DeviceArgs a) {
+  const int p = a.prob_order[blockIdx.x];
   const int chain = uniform_i(wave_id()) & 1; /* uniform per wave: say so (scalar branches) */
   const int lane = lane_id();
   const int contig = a.prob_contig[p];
@@ -609,5 +547,5 @@ __global__ void math_probe_kernel(int op, int n, const double *x, double *y) {
   if (i < n) y[i] = op == 0 ? d_exp(x[i]) : d_log(x[i]);
 }
 
+}  // namespace PSD_VARIANT
 }  // namespace psd
-#endif

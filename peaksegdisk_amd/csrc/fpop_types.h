@@ -1,0 +1,75 @@
+/* fpop_types.h -- what the host driver and every build variant of the kernels share: problem
+ * status codes, per-problem results and the kernel argument block.
+ */
+#ifndef PSD_FPOP_TYPES_H
+#define PSD_FPOP_TYPES_H
+
+namespace psd {
+
+constexpr int N_PROF = 24; /* PSD_PROFILE builds: cycle counters per wave */
+
+constexpr int ARENA_CHUNK_LOG2 = 16;  /* arena is handed out in chunks of 65536 pieces */
+constexpr int ARENA_CHUNK = 1 << ARENA_CHUNK_LOG2;
+constexpr int FN_COUNT_BITS = 24;     /* fn_ref = (arena offset << 24) | piece count */
+
+/* problem status written by the kernels (0 = ok) */
+enum {
+  PST_OK = 0,
+  PST_LDS_OVERFLOW = 1,  /* a list outgrew LDS_CAP and the spill path is not available */
+  PST_ARENA_FULL = 2,    /* host retries with a larger arena */
+  PST_REF_THROW = 3,     /* the reference would throw / loop / read a list sentinel */
+  PST_BACKTRACK = 4,     /* findMean found no piece (the reference would never return) */
+};
+
+struct ProbResult {
+  double best_cost;       /* Minimize() of the last down function (drv:404-406) */
+  double best_log_mean;
+  double prev_log_mean;
+  int prev_seg_end;
+  int status;
+  int wave_err;           /* WERR_* bits for diagnostics */
+  int max_intervals;      /* drv:374-379 */
+  unsigned long long total_intervals; /* drv:373 */
+  int n_segments;         /* filled by the backtrack kernel */
+  int n_equality;         /* drv:411,436 */
+  int n_serial_env;       /* min-envelope calls that needed the sequential replay */
+  int step_reached;
+  int spill_steps;        /* data points processed with the lists in the HBM spill area */
+};
+
+struct DeviceArgs {
+  int n_problems;
+  /* per problem */
+  const int *prob_contig;
+  const double *prob_penalty;
+  const long long *prob_fn_off;  /* into fn_ref: 2*N entries (up: [0,N), down: [N,2N)) */
+  const long long *prob_seg_off; /* into seg_start / seg_mean: N+1 entries */
+  const int *prob_order;         /* workgroup b solves problem prob_order[b]: longest first */
+  ProbResult *result;
+  /* per contig */
+  const int *contig_n;
+  const long long *contig_off; /* into count / weight */
+  const double *contig_min_log_mean;
+  const double *contig_max_log_mean;
+  const int *count;  /* 4th bedGraph column */
+  const int *weight; /* chromEnd - chromStart */
+  /* arena: the in-HBM cost-function store */
+  double *ar_mx;
+  double *ar_prv;
+  int *ar_di;
+  unsigned long long ar_cap; /* pieces */
+  unsigned long long *ar_next_chunk;
+  unsigned long long *fn_ref;
+  /* segment tables, in backtrack order */
+  int *seg_start;   /* data index whose chromEnd starts the segment; -1 = first_chromStart */
+  double *seg_mean; /* exp(best_log_mean) */
+  long long *prof;  /* PSD_PROFILE builds: per (problem, wave) cycle counters, else NULL */
+  /* spill area for functions with more than LDS_CAP pieces: per problem 48*spill_cap doubles
+   * (6 lists x 6 fields + 2 waves x 6 scratch arrays) and 12*spill_cap ints */
+  double *spill_f64;
+  int *spill_i32;
+  int spill_cap;
+};
+
+}  // namespace psd
+#endif

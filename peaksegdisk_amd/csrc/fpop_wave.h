@@ -27,18 +27,26 @@
  * The three operations are out-of-line functions returning the piece count (>= 0) or
  * -(WERR_* bits): the fully inlined kernel was ~200 KB of code against a 64 KB I-cache.
  */
-#ifndef PSD_FPOP_WAVE_H
-#define PSD_FPOP_WAVE_H
-
 #include "fpop_pieces.h"
+#include "fpop_types.h"
+
+/* NO include guard: everything below is compiled once per build variant, into namespace
+ * psd::PSD_VARIANT.  The includer defines
+ *   PSD_VARIANT       namespace of this variant (lat, thr)
+ *   PSD_LDS_CAP       pieces per LDS-resident list
+ *   PSD_HELPER_WAVES  defined: 4 waves per workgroup (two chains + their helper waves) */
+#if !defined(PSD_VARIANT) || !defined(PSD_LDS_CAP)
+#error "define PSD_VARIANT and PSD_LDS_CAP before including fpop_wave.h / fpop_kernels.h"
+#endif
 
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
 
 namespace psd {
+namespace PSD_VARIANT {
 
-constexpr int LDS_CAP = 128; /* pieces per LDS-resident list */
+constexpr int LDS_CAP = PSD_LDS_CAP; /* pieces per LDS-resident list */
 
 /* one piece list, struct-of-arrays (fields of funPieceListLog.h:11-34) */
 struct ListStore {
@@ -53,9 +61,6 @@ struct ScratchStore {
   int cls[LDS_CAP];
   int iv[2 * LDS_CAP];
 };
-#if !defined(PSD_NO_HELPER_WAVES) && !defined(PSD_HELPER_WAVES)
-#define PSD_HELPER_WAVES 1 /* the shipped configuration; -DPSD_NO_HELPER_WAVES for A/B runs */
-#endif
 /* Helper waves (PSD_HELPER_WAVES): every chain's main wave has a second wave that evaluates
  * independent parts of the envelope classification concurrently -- the mean-space midpoint
  * cost while the main wave computes the optimum of the difference piece, and the larger-root
@@ -70,7 +75,6 @@ struct Mail {
   double res_mid[64], res_large[64];
 };
 
-constexpr int N_PROF = 24;
 /* the workgroup's LDS: lists 0,1 = up (double-buffered), 2,3 = down, 4,5 = per-wave
  * min-less / min-more result */
 struct SharedBlock {
@@ -1829,5 +1833,5 @@ PSD_NOINLINE int min_env_wave(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, 
   return n_out;
 }
 
+}  // namespace PSD_VARIANT
 }  // namespace psd
-#endif

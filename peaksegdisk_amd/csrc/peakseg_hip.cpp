@@ -11,9 +11,31 @@
  */
 #include "../../include/peaksegdisk_hip.h"
 
+/* Two builds of the same kernel source:
+ *   lat  latency build: 128 pieces per LDS list and a helper wave per chain (4 waves per
+ *        workgroup, 2 workgroups per CU).  Fastest per problem; used while every problem of
+ *        the set can be resident at once (the 64-penalty grid of one contig runs here).
+ *   thr  throughput build: 64 pieces per LDS list, no helper waves (2 waves per workgroup,
+ *        4 workgroups per CU).  ~7% slower per problem, twice the problems per CU; used for
+ *        sets that oversubscribe the chip (many contigs x many penalties).
+ * Both produce identical results. */
+#define PSD_VARIANT lat
+#define PSD_LDS_CAP 128
+#ifndef PSD_NO_HELPER_WAVES /* -DPSD_NO_HELPER_WAVES: A/B builds (tools/ab_libs.py) */
+#define PSD_HELPER_WAVES 1
+#endif
 #include "fpop_kernels.h"
+#undef PSD_VARIANT
+#undef PSD_LDS_CAP
+#undef PSD_HELPER_WAVES
+#define PSD_VARIANT thr
+#define PSD_LDS_CAP 64
+#include "fpop_kernels.h"
+#undef PSD_VARIANT
+#undef PSD_LDS_CAP
 
 #include <errno.h>
+#include <algorithm>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -225,6 +247,8 @@ struct psd_problem_set {
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   std::vector<psd::ProbResult> results;
   bool solved = false;
+  int n_cu = 0;            /* compute units of the device */
+  bool throughput = false; /* which kernel build the last solve used */
   std::vector<void *> allocs;
   unsigned long long bytes = 0;
 };
@@ -310,6 +334,10 @@ extern "C" void peakseg_hip_problem_set_destroy(psd_problem_set *s) {
   delete s;
 }
 
+extern "C" const char *peakseg_hip_problem_set_kernel_build(psd_problem_set *s) {
+  return s->throughput ? "thr" : "lat";
+}
+
 extern "C" unsigned long long peakseg_hip_problem_set_bytes(psd_problem_set *s) {
   return s ? s->bytes : 0;
 }
@@ -378,6 +406,14 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
   }
   s->fn_total = fn_off;
   s->seg_total = seg_off;
+  /* workgroups are dispatched in index order: start the longest problems first so that a
+   * set of unequal contigs does not end with one long problem running alone */
+  std::vector<int> order((size_t)n_problems);
+  for (int p = 0; p < n_problems; p++) order[(size_t)p] = p;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+    return s->contig_n[(size_t)s->prob_contig[(size_t)x]] >
+           s->contig_n[(size_t)s->prob_contig[(size_t)y]];
+  });
   int st = 0;
   psd::DeviceArgs &d = s->d;
   d.n_problems = n_problems;
@@ -385,6 +421,7 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
       (st = dev_upload(s, &d.prob_penalty, s->prob_penalty)) ||
       (st = dev_upload(s, &d.prob_fn_off, s->prob_fn_off)) ||
       (st = dev_upload(s, &d.prob_seg_off, s->prob_seg_off)) ||
+      (st = dev_upload(s, &d.prob_order, order)) ||
       (st = dev_upload(s, &d.contig_n, s->contig_n)) ||
       (st = dev_upload(s, &d.contig_off, s->contig_off)) ||
       (st = dev_upload(s, &d.contig_min_log_mean, min_lm)) ||
@@ -404,7 +441,7 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
     int cap = 16384;
     if (const char *e = getenv("PEAKSEG_HIP_SPILL_CAP")) cap = atoi(e);
     if (cap > 65535) cap = 65535;
-    if (cap <= psd::LDS_CAP) cap = 0;
+    if (cap <= psd::lat::LDS_CAP) cap = 0;
     d.spill_cap = cap;
     d.spill_f64 = nullptr;
     d.spill_i32 = nullptr;
@@ -438,6 +475,10 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
     peakseg_hip_problem_set_destroy(s);
     return st;
   }
+  if (hipDeviceGetAttribute(&s->n_cu, hipDeviceAttributeMultiprocessorCount, device) !=
+          hipSuccess ||
+      s->n_cu <= 0)
+    s->n_cu = 256;
   hipError_t e = hipStreamCreate(&s->stream);
   for (auto &ev : s->ev)
     if (e == hipSuccess) e = hipEventCreate(&ev);
@@ -454,15 +495,26 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
 extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_ms,
                                              float *backtrack_ms) {
   HIP_TRY(hipSetDevice(s->device));
+  /* the latency build keeps 2 workgroups per CU resident: beyond that, problems would queue
+   * behind each other and the throughput build (4 per CU) finishes the set sooner.
+   * PEAKSEG_HIP_VARIANT=lat|thr overrides (tests, A/B runs). */
+  s->throughput = s->n_problems > 2 * s->n_cu;
+  if (const char *e = getenv("PEAKSEG_HIP_VARIANT")) {
+    if (!strcmp(e, "lat")) s->throughput = false;
+    if (!strcmp(e, "thr")) s->throughput = true;
+  }
   for (int attempt = 0;; attempt++) {
     HIP_TRY(hipMemsetAsync(s->d.ar_next_chunk, 0, sizeof(unsigned long long), s->stream));
     HIP_TRY(hipEventRecord(s->ev[0], s->stream));
-    hipLaunchKernelGGL(psd::fpop_forward_kernel, dim3((unsigned)s->n_problems),
-                       dim3(psd::FORWARD_THREADS), 0,
-                       s->stream, s->d);
+    if (s->throughput)
+      hipLaunchKernelGGL(psd::thr::fpop_forward_kernel, dim3((unsigned)s->n_problems),
+                         dim3(psd::thr::FORWARD_THREADS), 0, s->stream, s->d);
+    else
+      hipLaunchKernelGGL(psd::lat::fpop_forward_kernel, dim3((unsigned)s->n_problems),
+                         dim3(psd::lat::FORWARD_THREADS), 0, s->stream, s->d);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[1], s->stream));
-    hipLaunchKernelGGL(psd::fpop_backtrack_kernel, dim3((unsigned)s->n_problems), dim3(64), 0,
+    hipLaunchKernelGGL(psd::lat::fpop_backtrack_kernel, dim3((unsigned)s->n_problems), dim3(64), 0,
                        s->stream, s->d);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[2], s->stream));
@@ -657,7 +709,7 @@ extern "C" int peakseg_hip_math_probe(int op, int n, const double *x, double *y)
   HIP_TRY(hipMalloc(&dx, (size_t)n * 8));
   HIP_TRY(hipMalloc(&dy, (size_t)n * 8));
   HIP_TRY(hipMemcpy(dx, x, (size_t)n * 8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(psd::math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+  hipLaunchKernelGGL(psd::lat::math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t) nullptr, op, n, dx, dy);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());

@@ -66,6 +66,11 @@ class ProblemSet:
             raise RuntimeError("export_db failed")
 
     @property
+    def kernel_build(self):
+        """'lat' or 'thr': which build of the forward kernel the last solve() used."""
+        return self._lib.peakseg_hip_problem_set_kernel_build(self._h).decode()
+
+    @property
     def hbm_bytes(self):
         return int(self._lib.peakseg_hip_problem_set_bytes(self._h))
 

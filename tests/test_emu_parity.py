@@ -24,10 +24,7 @@ def psd():
     subprocess.run(["make", "-s", "-C", EMU_DIR], check=True)
     import peaksegdisk_amd
     from peaksegdisk_amd import _native
-    # PSD_EMU_VARIANT=_nohelper rehearses the build without helper waves
-    name = "libpeaksegdisk_emu%s.so" % os.environ.get("PSD_EMU_VARIANT", "")
-    subprocess.run(["make", "-s", "-C", EMU_DIR, "_build/" + name], check=True)
-    emu = _native.declare(ctypes.CDLL(os.path.join(EMU_DIR, "_build", name)))
+    emu = _native.declare(ctypes.CDLL(os.path.join(EMU_DIR, "_build", "libpeaksegdisk_emu.so")))
     real = _native.lib
     _native.lib = emu
     try:
@@ -101,30 +98,8 @@ def test_emu_newton_step_cap_fallback(oracle_det, tmp_path):
     pset.close()
 
 
-def test_emu_without_helper_waves(oracle_det, tmp_path):
-    """-DPSD_NO_HELPER_WAVES (2 waves per workgroup, the A/B configuration of
-    tools/ab_libs.py) computes the same store as the shipped 4-wave kernel."""
-    import numpy as np
-    import peaksegdisk_amd  # noqa: F401
-    from peaksegdisk_amd import _native, synthetic
-    from peaksegdisk_amd.grid import ProblemSet
-    subprocess.run(["make", "-s", "-C", EMU_DIR, "all"], check=True)
-    lib = _native.declare(ctypes.CDLL(os.path.join(EMU_DIR, "_build",
-                                                   "libpeaksegdisk_emu_nohelper.so")))
-    cs, ce, cnt = synthetic.poisson_coverage(1500, seed=5)
-    pens = ["0.3", "25", "4000"]
-    pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, float(p)) for p in pens],
-                      lib=lib)
-    pset.solve()
-    bg = str(tmp_path / "coverage.bedGraph")
-    synthetic.write_bedgraph(bg, cs, ce, cnt)
-    for i, pen in enumerate(pens):
-        want = str(tmp_path / ("o_%d.db" % i))
-        assert oracle_det.solve(bg, pen, want) == 0
-        got = str(tmp_path / ("g_%d.db" % i))
-        pset.export_db(i, ce, got)
-        assert open(got, "rb").read() == open(want, "rb").read(), pen
-    pset.close()
+def test_emu_throughput_build(psd, oracle_det, tmp_path, monkeypatch):
+    gp.test_throughput_build_identical(psd, oracle_det, tmp_path, monkeypatch, 400, 4)
 
 
 def test_emu_grid_properties_small(psd):

@@ -245,6 +245,55 @@ def test_adversarial_increasing_counts_spill(psd, oracle_det, tmp_path, n_bins):
 
 
 @GPU
+@pytest.mark.parametrize("n_bins,n_contigs", [(3000, 72)])
+def test_throughput_build_identical(psd, oracle_det, tmp_path, monkeypatch, n_bins, n_contigs):
+    """The library carries two builds of the forward kernel (peakseg_hip.cpp): "lat" (helper
+    waves, 128 pieces per LDS list) for sets that fit the chip at 2 workgroups per CU, "thr"
+    (no helper waves, 64 pieces per LDS list, 4 workgroups per CU) beyond that.  Same results:
+    a set large enough to pick "thr" by itself is compared with the same set forced onto
+    "lat", and one contig's stored functions with the oracle's db byte for byte."""
+    from peaksegdisk_amd import ProblemSet, synthetic
+    contigs, ends = [], []
+    for k in range(n_contigs):
+        cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=50 + k)
+        contigs.append((cnt, (ce - cs).astype(np.int32)))
+        ends.append((cs, ce, cnt))
+    pens = ["0.2", "3", "45", "600", "2500", "8000", "30000", "90000"]
+    problems = [(k, float(p)) for k in range(n_contigs) for p in pens]
+    monkeypatch.delenv("PEAKSEG_HIP_VARIANT", raising=False)
+    auto = ProblemSet(contigs, problems)
+    auto.solve()
+    want = "thr" if len(problems) > 512 else "lat"
+    assert auto.kernel_build == want
+    monkeypatch.setenv("PEAKSEG_HIP_VARIANT", "lat" if want == "thr" else "thr")
+    other = ProblemSet(contigs, problems)
+    other.solve()
+    assert other.kernel_build != auto.kernel_build
+    monkeypatch.delenv("PEAKSEG_HIP_VARIANT")
+    for p in range(len(problems)):
+        ra, rb = auto.result(p), other.result(p)
+        assert ra.status == 0 and rb.status == 0
+        assert (ra.n_segments, ra.max_intervals, ra.total_intervals, ra.best_cost) == \
+               (rb.n_segments, rb.max_intervals, rb.total_intervals, rb.best_cost)
+        sa, ma = auto.segments(p)
+        sb, mb = other.segments(p)
+        assert np.array_equal(sa, sb) and np.array_equal(ma.view(np.uint64), mb.view(np.uint64))
+    # contig 0 against the oracle, stored functions included, from both builds
+    cs, ce, cnt = ends[0]
+    bg = str(tmp_path / "coverage.bedGraph")
+    synthetic.write_bedgraph(bg, cs, ce, cnt)
+    for i, pen in enumerate(pens):
+        db_o = str(tmp_path / ("oracle_%d.db" % i))
+        assert oracle_det.solve(bg, pen, db_o) == 0
+        for name, ps in (("auto", auto), ("other", other)):
+            db_g = str(tmp_path / ("%s_%d.db" % (name, i)))
+            ps.export_db(i, ce, db_g)
+            assert open(db_g, "rb").read() == open(db_o, "rb").read(), (name, pen)
+    auto.close()
+    other.close()
+
+
+@GPU
 def test_full_size_grid_properties(psd, oracle_det, tmp_path):
     """BASELINE.json configs[1] at full size (1e6 bins x 64 penalties): properties that do not
     need the oracle at that size, plus two penalties checked against the oracle outright.

@@ -1,15 +1,35 @@
-import ctypes, sys, os, time
-sys.path.insert(0, os.getcwd())
+#!/usr/bin/env python3
+"""Diagnostic A/B: time the forward kernel of several builds of the HIP library on the same
+problem set.  usage: python tools/ab_libs.py [--bins N] [--contigs C] lib1.so lib2.so ...
+(C contigs of N bins x 64 penalties = 64*C problems in one launch; C=1 is the latency-bound
+bench workload, C>=8 fills the chip)."""
+import argparse
+import ctypes
+import os
+import sys
+
 import numpy as np
-from peaksegdisk_amd import _native, synthetic
-from peaksegdisk_amd.grid import ProblemSet
-cs, ce, cnt = synthetic.poisson_coverage(100000, seed=1)
-w=(ce-cs).astype(np.int32)
-pens=synthetic.penalty_grid(64)
-for name in sys.argv[1:]:
-    lib=_native.declare(ctypes.CDLL(os.path.abspath(name)))
-    ps=ProblemSet([(cnt,w)],[(0,float(p)) for p in pens],lib=lib)
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from peaksegdisk_amd import _native, synthetic  # noqa: E402
+from peaksegdisk_amd.grid import ProblemSet  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--bins", type=int, default=100000)
+ap.add_argument("--contigs", type=int, default=1)
+ap.add_argument("libs", nargs="+")
+args = ap.parse_args()
+contigs = []
+for k in range(args.contigs):
+    cs, ce, cnt = synthetic.poisson_coverage(args.bins, seed=1 + k)
+    contigs.append((cnt, (ce - cs).astype(np.int32)))
+pens = synthetic.penalty_grid(64)
+problems = [(k, float(p)) for k in range(args.contigs) for p in pens]
+for name in args.libs:
+    lib = _native.declare(ctypes.CDLL(os.path.abspath(name)))
+    ps = ProblemSet(contigs, problems, lib=lib)
     ps.solve()
-    f=[ps.solve()[0] for _ in range(2)]
-    print(name, "forward ms", min(f), "=> bins/s", 100000*64/(min(f)/1e3))
+    f = [ps.solve()[0] for _ in range(2)]
+    print(name, "forward ms", min(f), "=> bins/s", args.bins * len(problems) / (min(f) / 1e3),
+          flush=True)
     ps.close()
