@@ -187,6 +187,7 @@ def main():
                 "mean_intervals": total_pieces / (2.0 * args.bins * args.penalties),
             },
             "hbm_bytes_resident": pset.hbm_bytes,
+            "kernel_build": pset.kernel_build,
             "serial_env_replays": int(sum(r.n_serial_env for r in results)),
         }
         if not args.no_cpu:
