@@ -90,7 +90,9 @@ int peakseg_hip_problem_set_create(int device, int n_contigs, const int *contig_
                                    unsigned long long arena_pieces, psd_problem_set **out);
 
 /* Run forward DP + backtrack for every problem of the set; inputs are already resident.
- * Kernel durations are measured with HIP events on the stream the kernels run on. */
+ * *forward_ms = duration of the kernel, measured with HIP events on the stream it runs on.
+ * Each workgroup decodes its segmentation right after its last data point, inside the same
+ * kernel, so there is no separate backtrack launch: *backtrack_ms is always 0. */
 int peakseg_hip_problem_set_solve(psd_problem_set *set, float *forward_ms, float *backtrack_ms);
 
 int peakseg_hip_problem_set_result(psd_problem_set *set, int problem, psd_result *out);

@@ -9,8 +9,9 @@
  *                         backtrack record {max_log_mean, data_i, prev_log_mean} per piece --
  *                         what the reference serialises to its DiskVector (drv:12-34) -- is
  *                         appended to the in-HBM arena.
- *   fpop_backtrack_kernel one wavefront per problem decodes the segmentation from the arena
- *                         (drv:399-442: Minimize result, then findMean per segment).
+ *                         After its last data point the down wave decodes the segmentation
+ *                         from the arena (backtrack_wave; drv:399-442: Minimize result, then
+ *                         findMean per segment).
  *   math_probe_kernel     element-wise psd_exp / psd_log (tests: host == device bit for bit).
  *
  * Included by peakseg_hip.cpp (hipcc, gfx950) and by tests/emu (g++ + hip_emu.h).
@@ -254,6 +255,80 @@ PSD_D int chain_step(const DeviceArgs &a, ArenaCursor &cur, unsigned long long f
  * every function has at most LDS_CAP pieces; when an operation overflows, the step is redone
  * with all lists in the HBM spill area, and the problem returns to LDS once both functions
  * have shrunk below LDS_CAP/2. */
+/* Decode the optimal segmentation (drv:399-442): one wave, right after the forward pass of
+ * its problem (the arena records it follows were written by this workgroup; fast problems
+ * decode while slower ones are still in their forward pass). */
+PSD_D void backtrack_wave(const DeviceArgs &a, int p, ProbResult &r) {
+  const int lane = lane_id();
+  const int N = a.contig_n[a.prob_contig[p]];
+  const unsigned long long fn0 = (unsigned long long)a.prob_fn_off[p];
+  int *seg_start = a.seg_start + a.prob_seg_off[p];
+  double *seg_mean = a.seg_mean + a.prob_seg_off[p];
+  double best_log_mean = r.best_log_mean;
+  double prev_log_mean = r.prev_log_mean;
+  int prev_seg_end = r.prev_seg_end;
+  int prev_seg_offset = 0;
+  int n_seg = 0, n_eq = 0, status = 0;
+  while (0 <= prev_seg_end) {
+    if (n_seg >= N) { /* more segments than data points: cannot happen for a valid store */
+      status = PST_BACKTRACK;
+      break;
+    }
+    unsigned long long ref = a.fn_ref[fn0 + (unsigned long long)(prev_seg_offset + prev_seg_end)];
+    unsigned long long off = ref >> FN_COUNT_BITS;
+    int n = (int)(ref & ((1ull << FN_COUNT_BITS) - 1));
+    if (lane == 0) {
+      seg_start[n_seg] = prev_seg_end;
+      seg_mean[n_seg] = d_exp(best_log_mean);
+    }
+    n_seg++;
+    prev_seg_offset = prev_seg_offset == 0 ? N : 0;
+    if (prev_log_mean != PSD_INF) {
+      best_log_mean = prev_log_mean; /* equality constraint inactive */
+    } else {
+      n_eq++;
+    }
+    /* findMean (fpl:643-653) on the restored function (drv:44-54): piece k spans
+     * [max_{k-1}, max_k], the first from -Inf; the first match wins. */
+    bool found = false;
+    for (int base = 0; base < n; base += WAVE) {
+      int k = base + lane;
+      bool hit = false;
+      int di = 0;
+      double prv = 0.0;
+      if (k < n) {
+        double mxk = a.ar_mx[off + k];
+        double mnk = k == 0 ? -PSD_INF : a.ar_mx[off + k - 1];
+        di = a.ar_di[off + k];
+        prv = a.ar_prv[off + k];
+        hit = mnk <= best_log_mean && best_log_mean <= mxk;
+      }
+      unsigned long long m = ballot(hit);
+      if (m) {
+        int src = ctz64(m);
+        prev_seg_end = rdlane_i(di, src);
+        prev_log_mean = rdlane_d(prv, src);
+        found = true;
+        break;
+      }
+    }
+    if (!found) {
+      status = PST_BACKTRACK;
+      break;
+    }
+  }
+  if (status == 0) {
+    if (lane == 0) {
+      seg_start[n_seg] = -1;
+      seg_mean[n_seg] = d_exp(best_log_mean);
+    }
+    n_seg++;
+  }
+  r.n_segments = n_seg;
+  r.n_equality = n_eq;
+  r.status = status;
+}
+
 #ifdef PSD_HELPER_WAVES
 constexpr bool USE_HELPER = true;
 constexpr int FORWARD_THREADS = 256; /* waves 0,1: the two chains; waves 2,3: their helpers */
@@ -424,6 +499,7 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_OCC void fpop_forward_kernel(D
     g_sm.total_up = total_intervals;
     g_sm.max_up = max_intervals;
   }
+  device_fence(); /* the stored functions of both chains are read back by backtrack_wave */
   block_sync(chain);
 #ifdef PSD_HELPER_WAVES
   if (mail_wait(chain)) mail_post(chain, HOP_EXIT);
@@ -460,84 +536,9 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_OCC void fpop_forward_kernel(D
         minimize_wave(lds_list(id), g_sm.n[id], &r.best_cost, &r.best_log_mean, &r.prev_seg_end,
                       &r.prev_log_mean);
       }
+      backtrack_wave(a, p, r);
     }
     if (lane == 0) a.result[p] = r;
-  }
-}
-
-/* Decode the optimal segmentation (drv:399-442). */
-__global__ __launch_bounds__(64) void fpop_backtrack_kernel(DeviceArgs a) {
-  const int p = (int)blockIdx.x;
-  const int lane = lane_id();
-  psd_tables_init(); /* exp/log tables -> LDS (segment means are exp(log-mean)) */
-  ProbResult r = a.result[p];
-  if (r.status != 0) return;
-  const int N = a.contig_n[a.prob_contig[p]];
-  const unsigned long long fn0 = (unsigned long long)a.prob_fn_off[p];
-  int *seg_start = a.seg_start + a.prob_seg_off[p];
-  double *seg_mean = a.seg_mean + a.prob_seg_off[p];
-  double best_log_mean = r.best_log_mean;
-  double prev_log_mean = r.prev_log_mean;
-  int prev_seg_end = r.prev_seg_end;
-  int prev_seg_offset = 0;
-  int n_seg = 0, n_eq = 0, status = 0;
-  while (0 <= prev_seg_end) {
-    if (n_seg >= N) { /* more segments than data points: cannot happen for a valid store */
-      status = PST_BACKTRACK;
-      break;
-    }
-    unsigned long long ref = a.fn_ref[fn0 + (unsigned long long)(prev_seg_offset + prev_seg_end)];
-    unsigned long long off = ref >> FN_COUNT_BITS;
-    int n = (int)(ref & ((1ull << FN_COUNT_BITS) - 1));
-    if (lane == 0) {
-      seg_start[n_seg] = prev_seg_end;
-      seg_mean[n_seg] = d_exp(best_log_mean);
-    }
-    n_seg++;
-    prev_seg_offset = prev_seg_offset == 0 ? N : 0;
-    if (prev_log_mean != PSD_INF) {
-      best_log_mean = prev_log_mean; /* equality constraint inactive */
-    } else {
-      n_eq++;
-    }
-    /* findMean (fpl:643-653) on the restored function (drv:44-54): piece k spans
-     * [max_{k-1}, max_k], the first from -Inf; the first match wins. */
-    bool found = false;
-    for (int base = 0; base < n; base += WAVE) {
-      int k = base + lane;
-      bool hit = false;
-      int di = 0;
-      double prv = 0.0;
-      if (k < n) {
-        double mxk = a.ar_mx[off + k];
-        double mnk = k == 0 ? -PSD_INF : a.ar_mx[off + k - 1];
-        di = a.ar_di[off + k];
-        prv = a.ar_prv[off + k];
-        hit = mnk <= best_log_mean && best_log_mean <= mxk;
-      }
-      unsigned long long m = ballot(hit);
-      if (m) {
-        int src = ctz64(m);
-        prev_seg_end = rdlane_i(di, src);
-        prev_log_mean = rdlane_d(prv, src);
-        found = true;
-        break;
-      }
-    }
-    if (!found) {
-      status = PST_BACKTRACK;
-      break;
-    }
-  }
-  if (lane == 0) {
-    if (status == 0) {
-      seg_start[n_seg] = -1;
-      seg_mean[n_seg] = d_exp(best_log_mean);
-      n_seg++;
-    }
-    a.result[p].n_segments = n_seg;
-    a.result[p].n_equality = n_eq;
-    a.result[p].status = status;
   }
 }
 

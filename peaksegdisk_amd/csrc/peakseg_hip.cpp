@@ -244,7 +244,7 @@ struct psd_problem_set {
   bool arena_auto = true;
   psd::DeviceArgs d{};
   hipStream_t stream = nullptr;
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
   std::vector<psd::ProbResult> results;
   bool solved = false;
   int n_cu = 0;            /* compute units of the device */
@@ -514,16 +514,11 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
                          dim3(psd::lat::FORWARD_THREADS), 0, s->stream, s->d);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[1], s->stream));
-    hipLaunchKernelGGL(psd::lat::fpop_backtrack_kernel, dim3((unsigned)s->n_problems), dim3(64), 0,
-                       s->stream, s->d);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(s->ev[2], s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    float f_ms = 0.f, b_ms = 0.f;
+    float f_ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&f_ms, s->ev[0], s->ev[1]));
-    HIP_TRY(hipEventElapsedTime(&b_ms, s->ev[1], s->ev[2]));
     if (forward_ms) *forward_ms = f_ms;
-    if (backtrack_ms) *backtrack_ms = b_ms;
+    if (backtrack_ms) *backtrack_ms = 0.f; /* decoding happens inside the forward kernel */
     HIP_TRY(hipMemcpy(s->results.data(), s->d.result,
                       sizeof(psd::ProbResult) * (size_t)s->n_problems, hipMemcpyDeviceToHost));
     bool arena_full = false;

@@ -105,6 +105,7 @@ PSD_D long long cycle_now() { return (long long)__builtin_readcyclecounter(); }
 PSD_D int flag_load(const int *p) { return *(const volatile int *)p; }
 PSD_D void flag_store(int *p, int v) { *(volatile int *)p = v; }
 PSD_D void spin_pause() { emu::yield_fiber(); }
+PSD_D void device_fence() {}
 #else
 PSD_D int flag_load(const int *p) {
   return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -113,6 +114,8 @@ PSD_D void flag_store(int *p, int v) {
   __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 PSD_D void spin_pause() { __builtin_amdgcn_s_sleep(1); }
+/* make this thread's global stores visible to the other waves of the device */
+PSD_D void device_fence() { __threadfence(); }
 #endif
 
 template <class T>
