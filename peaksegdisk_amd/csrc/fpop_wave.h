@@ -66,13 +66,12 @@ struct ScratchStore {
  * cost while the main wave computes the optimum of the difference piece, and the larger-root
  * Newton solves while the main wave does the smaller-root ones.  Lane k of the helper works
  * on lane k's interval; arguments and results cross through this LDS mailbox. */
-enum { HOP_BARRIER = 1, HOP_EXIT = 2, HOP_MID = 3, HOP_LARGE = 4 };
+enum { HOP_BARRIER = 1, HOP_EXIT = 2, HOP_ROOT = 3 };
 struct Mail {
   int seq_cmd, seq_done, op, abort;
   int flags[64];
-  double d_lin[64], d_log[64], d_con[64], ea[64], eb[64]; /* HOP_MID (and kept for HOP_LARGE) */
-  double om[64], oc2[64], b[64], cr[64];                  /* HOP_LARGE */
-  double res_mid[64], res_large[64];
+  double d_lin[64], d_log[64], d_con[64], b[64]; /* HOP_ROOT: difference piece, right end */
+  double res_large[64];
 };
 
 /* the workgroup's LDS: lists 0,1 = up (double-buffered), 2,3 = down, 4,5 = per-wave
@@ -1284,38 +1283,38 @@ PSD_D void env_classify_lanes(bool valid, const Coef &c1, const Coef &c2, double
   const bool triv = same_funs(c1, c2);  /* fpl:945-951 */
   const bool act = valid && !triv;
   PSD_PROF_T0();
-  /* phase A/B: exp(a), exp(b), cost at the mean-space midpoint (fpl:960-961) */
-  double ea = 0.0, eb = 0.0, cost_diff_mid = 0.0;
-  if (act) {
-    ea = d_exp(a);
-    eb = d_exp(b);
-  }
-  bool mid_posted = false;
-#ifdef PSD_HELPER_WAVES
-  if (HELP) {
-    if (ballot(act)) { /* the helper evaluates the midpoint cost meanwhile */
-      Mail &m = g_sm.mail[chain];
-      const int l = lane_id();
-      m.flags[l] = act ? 1 : 0;
-      m.d_lin[l] = d.Linear;
-      m.d_log[l] = d.Log;
-      m.d_con[l] = d.Constant;
-      m.ea[l] = ea;
-      m.eb[l] = eb;
-      mail_post(chain, HOP_MID);
-      mid_posted = true;
-    }
-  } else
-#endif
-  {
-    if (act) cost_diff_mid = get_cost(d, d_log((eb + ea) / 2));
-  }
-  PSD_PROF_ADD(PROF_C_MID);
   const bool both = same_at_left && same_at_right;
   const bool hard = act && !both;
   const bool degen = hard && d.Log == 0;                              /* fpl:973-1019 */
   const bool degen_root = degen && d.Linear != 0 && d.Constant != 0;  /* fpl:996 */
   const bool rootp = hard && d.Log != 0;
+  bool root_posted = false;
+#ifdef PSD_HELPER_WAVES
+  if (HELP) {
+    /* The helper wave starts on the larger roots (fpl:1027) right away: it derives the
+     * optimum of the difference piece and has_two_roots itself -- same code, same bits --
+     * while this wave evaluates the end costs, the midpoint and the smaller roots. */
+    if (ballot(rootp)) {
+      Mail &m = g_sm.mail[chain];
+      const int l = lane_id();
+      m.flags[l] = rootp ? 1 : 0;
+      m.d_lin[l] = d.Linear;
+      m.d_log[l] = d.Log;
+      m.d_con[l] = d.Constant;
+      m.b[l] = b;
+      mail_post(chain, HOP_ROOT);
+      root_posted = true;
+    }
+  }
+#endif
+  /* phase A/B: exp(a), exp(b), cost at the mean-space midpoint (fpl:960-961) */
+  double ea = 0.0, eb = 0.0, cost_diff_mid = 0.0;
+  if (act) {
+    ea = d_exp(a);
+    eb = d_exp(b);
+    cost_diff_mid = get_cost(d, d_log((eb + ea) / 2));
+  }
+  PSD_PROF_ADD(PROF_C_MID);
   /* phase C: one log site for the degenerate crossing and for argmin() of the difference */
   const double larg = degen ? (-d.Constant / d.Linear) : (-d.Log / d.Linear);
   double lres = 0.0;
@@ -1338,41 +1337,25 @@ PSD_D void env_classify_lanes(bool valid, const Coef &c1, const Coef &c2, double
   /* phases E, F: the two Newton solves (fpl:1023-1028) */
   double smaller_log_mean = PSD_INF, larger_log_mean = PSD_INF;
   int it_small = 0, it_large = 0;
-  bool large_posted = false;
-#ifdef PSD_HELPER_WAVES
-  if (HELP) {
-    Mail &m = g_sm.mail[chain];
-    const int l = lane_id();
-    if (mid_posted) {
-      if (!mail_wait(chain)) err |= WERR_HELPER;
-      cost_diff_mid = m.res_mid[l];
-    }
-    if (ballot(two_roots)) { /* larger roots on the helper, smaller roots here */
-      m.flags[l] = two_roots ? 2 : 0;
-      m.om[l] = o.mean;
-      m.oc2[l] = o.cost2;
-      m.b[l] = b;
-      m.cr[l] = cost_diff_right;
-      mail_post(chain, HOP_LARGE);
-      large_posted = true;
-    }
-  }
-#endif
   if (two_roots) smaller_log_mean = get_smaller_root(d, o, a, cost_diff_left, 0.0, &it_small);
   PSD_PROF_ADD(PROF_C_SMALL);
 #ifdef PSD_HELPER_WAVES
   if (HELP) {
-    if (large_posted) {
+    if (root_posted) {
       if (!mail_wait(chain)) err |= WERR_HELPER;
-      larger_log_mean = g_sm.mail[chain].res_large[lane_id()];
+      if (two_roots) {
+        /* the early exit of get_larger_root (fpl:75-79), which the helper leaves to us */
+        const bool beyond = (o.cost2 < cost_diff_right && cost_diff_right < 0.0) ||
+                            (o.cost2 > cost_diff_right && cost_diff_right > 0.0);
+        larger_log_mean = beyond ? b + 1 : g_sm.mail[chain].res_large[lane_id()];
+      }
     }
   } else
 #endif
   {
     if (two_roots) larger_log_mean = get_larger_root(d, o, b, cost_diff_right, 0.0, &it_large);
   }
-  (void)large_posted;
-  (void)mid_posted;
+  (void)root_posted;
   PSD_PROF_ADD(PROF_C_LARGE);
   PSD_PROF_ITERS(PROF_IT_SMALL, it_small);
   PSD_PROF_ITERS(PROF_IT_LARGE, it_large);
@@ -1556,16 +1539,22 @@ PSD_D void helper_loop(int chain) {
     if (op == HOP_EXIT) return;
     if (op == HOP_BARRIER) {
       __syncthreads();
-    } else if (op == HOP_MID) {
+    } else if (op == HOP_ROOT) {
       if (m.flags[lane] & 1) {
-        Coef d = {m.d_lin[lane], m.d_log[lane], m.d_con[lane]};
-        m.res_mid[lane] = get_cost(d, d_log((m.eb[lane] + m.ea[lane]) / 2)); /* fpl:960-961 */
-      }
-    } else if (op == HOP_LARGE) {
-      if (m.flags[lane] & 2) {
-        Coef d = {m.d_lin[lane], m.d_log[lane], m.d_con[lane]};
-        PieceOpt o = {m.om[lane], 0.0, 0.0, m.oc2[lane]};
-        m.res_large[lane] = get_larger_root(d, o, m.b[lane], m.cr[lane], 0.0);
+        const Coef d = {m.d_lin[lane], m.d_log[lane], m.d_con[lane]};
+        /* the optimum of the difference piece exactly as env_classify_lanes derives it */
+        PieceOpt o;
+        o.mean = -d.Log / d.Linear;
+        o.log_mean = d_log(o.mean);
+        o.cost = get_cost(d, o.log_mean);
+        double loss_without_log_term = d.Linear * o.mean + d.Constant;
+        o.cost2 = loss_without_log_term + o.log_mean * d.Log;
+        const double b = m.b[lane];
+        double root = PSD_INF;
+        /* NaN as the right-end cost disables the early exit: the main wave applies it */
+        if (has_two_roots(d, o, 0.0)) root = get_larger_root(d, o, b, __builtin_nan(""), 0.0);
+        m.res_large[lane] = root;
+
       }
     }
     wave_sync();
