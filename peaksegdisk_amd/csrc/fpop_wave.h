@@ -464,24 +464,40 @@ PSD_NOINLINE int min_less_wave(L in_, int n_, L out_, int cap_, S s_, int data_i
   int my_base = 0; /* lane j: first task lane of start j */
   if (small) {
     unsigned long long m_start = ballot(lane < n && P.cls != CLS_STORE);
-    int total = 0;
-    for (unsigned long long m = m_start; m; m &= m - 1) {
-      int c = n - 1 - ctz64(m);
-      total += c < SPEC_WINDOW ? c : SPEC_WINDOW;
-    }
-    if (total > 0 && total <= WAVE) {
-      spec = true;
-      int tj = -1, tk = 0, base = 0;
-      for (unsigned long long m = m_start; m; m &= m - 1) {
-        int j = ctz64(m), cnt = n - 1 - j;
-        if (cnt > SPEC_WINDOW) cnt = SPEC_WINDOW;
-        if (lane == j) my_base = base;
-        if (lane >= base && lane < base + cnt) {
-          tj = j;
-          tk = j + 1 + (lane - base);
+    int tj = -1, tk = 0;
+    if (n * SPEC_WINDOW <= WAVE) {
+      /* few pieces (the usual case): task lane = start * SPEC_WINDOW + offset, no loop */
+      if (m_start) {
+        spec = true;
+        const int cj = lane / SPEC_WINDOW, off = lane - cj * SPEC_WINDOW;
+        if (cj < n && ((m_start >> cj) & 1ull) && cj + 1 + off < n) {
+          tj = cj;
+          tk = cj + 1 + off;
         }
-        base += cnt;
+        my_base = lane * SPEC_WINDOW;
       }
+    } else {
+      int total = 0;
+      for (unsigned long long m = m_start; m; m &= m - 1) {
+        int c = n - 1 - ctz64(m);
+        total += c < SPEC_WINDOW ? c : SPEC_WINDOW;
+      }
+      if (total > 0 && total <= WAVE) {
+        spec = true;
+        int base = 0;
+        for (unsigned long long m = m_start; m; m &= m - 1) {
+          int j = ctz64(m), cnt = n - 1 - j;
+          if (cnt > SPEC_WINDOW) cnt = SPEC_WINDOW;
+          if (lane == j) my_base = base;
+          if (lane >= base && lane < base + cnt) {
+            tj = j;
+            tk = j + 1 + (lane - base);
+          }
+          base += cnt;
+        }
+      }
+    }
+    if (spec) {
       bool inside = false, at_right = false, bad = false;
       int sp_steps = 0;
       if (tj >= 0) {
@@ -764,24 +780,40 @@ PSD_NOINLINE int min_more_wave(L in_, int n_, L out_, int cap_, S s_, int data_i
   PSD_PROF_SUB0();
   if (small) {
     unsigned long long m_start = ballot(lane < n && P.cls != CLS_STORE);
-    int total = 0;
-    for (unsigned long long m = m_start; m; m &= m - 1) {
-      int c = ctz64(m);
-      total += c < SPEC_WINDOW ? c : SPEC_WINDOW;
-    }
-    if (total > 0 && total <= WAVE) {
-      spec = true;
-      int tj = -1, tk = 0, base = 0;
-      for (unsigned long long m = m_start; m; m &= m - 1) {
-        int j = ctz64(m), cnt = j;
-        if (cnt > SPEC_WINDOW) cnt = SPEC_WINDOW;
-        if (lane == j) my_base = base;
-        if (lane >= base && lane < base + cnt) {
-          tj = j;
-          tk = j - 1 - (lane - base);
+    int tj = -1, tk = 0;
+    if (n * SPEC_WINDOW <= WAVE) {
+      /* few pieces (the usual case): task lane = start * SPEC_WINDOW + offset, no loop */
+      if (m_start & ~1ull) { /* piece 0 has no earlier piece */
+        spec = true;
+        const int cj = lane / SPEC_WINDOW, off = lane - cj * SPEC_WINDOW;
+        if (cj < n && ((m_start >> cj) & 1ull) && off < cj) {
+          tj = cj;
+          tk = cj - 1 - off;
         }
-        base += cnt;
+        my_base = lane * SPEC_WINDOW;
       }
+    } else {
+      int total = 0;
+      for (unsigned long long m = m_start; m; m &= m - 1) {
+        int c = ctz64(m);
+        total += c < SPEC_WINDOW ? c : SPEC_WINDOW;
+      }
+      if (total > 0 && total <= WAVE) {
+        spec = true;
+        int base = 0;
+        for (unsigned long long m = m_start; m; m &= m - 1) {
+          int j = ctz64(m), cnt = j;
+          if (cnt > SPEC_WINDOW) cnt = SPEC_WINDOW;
+          if (lane == j) my_base = base;
+          if (lane >= base && lane < base + cnt) {
+            tj = j;
+            tk = j - 1 - (lane - base);
+          }
+          base += cnt;
+        }
+      }
+    }
+    if (spec) {
       bool inside = false, at_left = false;
       int sp_steps = 0;
       PSD_PROF_SUB(PROF_S_ASSIGN);
