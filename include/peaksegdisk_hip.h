@@ -110,7 +110,7 @@ int peakseg_hip_problem_set_export_db(psd_problem_set *set, int problem, const i
                                       const char *path);
 
 /* Which build of the forward kernel the last solve used: "lat" (latency build: helper waves,
- * 2 workgroups per CU; sets of at most 2 problems per CU) or "thr" (throughput build:
+ * one workgroup per CU; sets of at most one problem per CU) or "thr" (throughput build:
  * 4 workgroups per CU).  Same results either way; the environment variable
  * PEAKSEG_HIP_VARIANT=lat|thr overrides the choice. */
 const char *peakseg_hip_problem_set_kernel_build(psd_problem_set *set);

@@ -220,10 +220,23 @@ PSD_D int chain_step(const DeviceArgs &a, ArenaCursor &cur, unsigned long long f
                      double pen_term, double cum_weight_prev, double w, int coverage,
                      double cum_weight) {
   int nm = 0;
+#ifdef PSD_CALL_LDS_OPS /* A/B: the LDS instantiations out of line as well */
+  constexpr bool inline_ops = false;
+#else
+  constexpr bool inline_ops = L::in_lds;
+#endif
   if (chain == 0) {
-    nm = min_less_wave(other_prev, n_other, mlist, cap, sc, t - 1, pen_term);
+    if constexpr (inline_ops) {
+      nm = min_less_impl(other_prev, n_other, mlist, cap, sc, t - 1, pen_term);
+    } else {
+      nm = min_less_wave(other_prev, n_other, mlist, cap, sc, t - 1, pen_term);
+    }
   } else if (t >= 2) {
-    nm = min_more_wave(other_prev, n_other, mlist, cap, sc, t - 1);
+    if constexpr (inline_ops) {
+      nm = min_more_impl(other_prev, n_other, mlist, cap, sc, t - 1);
+    } else {
+      nm = min_more_wave(other_prev, n_other, mlist, cap, sc, t - 1);
+    }
   }
   nm = uniform_i(nm); /* return values of out-of-line functions arrive in a VGPR */
   if (nm < 0) return nm;
@@ -238,7 +251,11 @@ PSD_D int chain_step(const DeviceArgs &a, ArenaCursor &cur, unsigned long long f
     }
   } else {
     const L f1 = chain == 0 ? mlist : mlist.shifted(cap - nm);
-    n_new = uniform_i(min_env_wave<HELP>(f1, nm, own_prev, n_own, own_new, cap, sc, chain));
+    if constexpr (inline_ops) {
+      n_new = uniform_i(min_env_impl<HELP>(f1, nm, own_prev, n_own, own_new, cap, sc, chain));
+    } else {
+      n_new = uniform_i(min_env_wave<HELP>(f1, nm, own_prev, n_own, own_new, cap, sc, chain));
+    }
   }
   if (n_new < 0) return n_new;
   PSD_PROF_T0();

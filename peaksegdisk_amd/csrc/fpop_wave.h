@@ -185,6 +185,7 @@ enum {
 
 /* accessor of an LDS-resident list: g_sm.list[id], elements off.. */
 struct LdsList {
+  static constexpr bool in_lds = true;
   int id, off;
   PSD_M double &Lin(int i) const { return g_sm.list[id].Lin[off + i]; }
   PSD_M double &Log(int i) const { return g_sm.list[id].Log[off + i]; }
@@ -231,6 +232,7 @@ struct LdsScratch {
 /* The same two accessors over HBM: the spill path for functions with more than LDS_CAP
  * pieces (adversarial data, vignettes/Worst_case.Rmd).  `cap` pieces per list. */
 struct GlobalList {
+  static constexpr bool in_lds = false;
   double *Lin_, *Log_, *Con_, *mn_, *mx_, *prv_;
   int *di_;
   PSD_M double &Lin(int i) const { return Lin_[i]; }
@@ -392,8 +394,8 @@ PSD_D void piece_costs_wave(const L &in, int n, const S &s, LanePiece &P) {
  * driver's set_prev_seg_end) and Constant += add_const (its add(0,0,penalty/cum_weight_prev),
  * PeakSegFPOPLog.cpp:290-296). */
 template <class L, class S>
-PSD_NOINLINE int min_less_wave(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
-                               double add_const_) {
+PSD_D int min_less_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
+                        double add_const_) {
   const L in = in_.uniformed(), out = out_.uniformed();
   const S s = s_.uniformed();
   const int n = uniform_i(n_), cap = uniform_i(cap_), data_i_out = uniform_i(data_i_out_);
@@ -723,7 +725,7 @@ PSD_NOINLINE int min_less_wave(L in_, int n_, L out_, int cap_, S s_, int data_i
 /* min-more: out(x) = min_{y>=x} in(y).  The reference builds the list with emplace_front;
  * here pieces are written downwards from out[cap-1]: the result is out[cap-n .. cap). */
 template <class L, class S>
-PSD_NOINLINE int min_more_wave(L in_, int n_, L out_, int cap_, S s_, int data_i_out_) {
+PSD_D int min_more_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_) {
   const L in = in_.uniformed(), out = out_.uniformed();
   const S s = s_.uniformed();
   const int n = uniform_i(n_), cap = uniform_i(cap_), data_i_out = uniform_i(data_i_out_);
@@ -1641,7 +1643,7 @@ PSD_NOINLINE int min_env_serial(L f1_, int n1_, L f2_, int n2_, L out_, int cap_
 
 /* min-envelope: out = pointwise min(f1, f2). */
 template <bool HELP, class L, class S>
-PSD_NOINLINE int min_env_wave(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, int chain_) {
+PSD_D int min_env_impl(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, int chain_) {
   const int chain = uniform_i(chain_);
   const L f1 = f1_.uniformed(), f2 = f2_.uniformed(), out = out_.uniformed();
   const S s = s_.uniformed();
@@ -1853,6 +1855,25 @@ PSD_NOINLINE int min_env_wave(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, 
   }
   return n_out;
 }
+
+/* The three operations, out of line (see the head of this file).  The kernel inlines the
+ * LDS instantiations into its loop -- one copy each, ~40 KB of code, and no call overhead
+ * (saving and restoring ~40 scalar and ~40 vector registers per call) -- and calls these
+ * wrappers for the HBM spill path. */
+template <class L, class S>
+PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
+                               double add_const) {
+  return min_less_impl(in, n, out, cap, s, data_i_out, add_const);
+}
+template <class L, class S>
+PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, S s, int data_i_out) {
+  return min_more_impl(in, n, out, cap, s, data_i_out);
+}
+template <bool HELP, class L, class S>
+PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap, S s, int chain) {
+  return min_env_impl<HELP>(f1, n1, f2, n2, out, cap, s, chain);
+}
+
 
 }  // namespace PSD_VARIANT
 }  // namespace psd

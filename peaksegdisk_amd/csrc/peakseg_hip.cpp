@@ -12,12 +12,14 @@
 #include "../../include/peaksegdisk_hip.h"
 
 /* Two builds of the same kernel source:
- *   lat  latency build: 128 pieces per LDS list and a helper wave per chain (4 waves per
- *        workgroup, 2 workgroups per CU).  Fastest per problem; used while every problem of
- *        the set can be resident at once (the 64-penalty grid of one contig runs here).
- *   thr  throughput build: 64 pieces per LDS list, no helper waves (2 waves per workgroup,
- *        4 workgroups per CU).  ~7% slower per problem, twice the problems per CU; used for
- *        sets that oversubscribe the chip (many contigs x many penalties).
+ *   lat  latency build: 128 pieces per LDS list, a helper wave per chain, and the piece-list
+ *        operations inlined into the kernel's loop (4 waves per workgroup, all registers of
+ *        the SIMDs: 1 workgroup per CU).  Fastest per problem; used while every problem of
+ *        the set gets a CU of its own (the 64-penalty grid of one contig runs here).
+ *   thr  throughput build: 64 pieces per LDS list, no helper waves, operations out of line
+ *        (2 waves per workgroup, 4 workgroups per CU).  ~12% slower per problem, four times
+ *        the problems per CU; used for sets that oversubscribe the chip (many contigs x many
+ *        penalties).
  * Both produce identical results. */
 #define PSD_VARIANT lat
 #define PSD_LDS_CAP 128
@@ -30,9 +32,17 @@
 #undef PSD_HELPER_WAVES
 #define PSD_VARIANT thr
 #define PSD_LDS_CAP 64
+#ifndef PSD_CALL_LDS_OPS
+#define PSD_CALL_LDS_OPS 1
+#define PSD_CALL_LDS_OPS_THR_ONLY 1
+#endif
 #include "fpop_kernels.h"
 #undef PSD_VARIANT
 #undef PSD_LDS_CAP
+#ifdef PSD_CALL_LDS_OPS_THR_ONLY
+#undef PSD_CALL_LDS_OPS
+#undef PSD_CALL_LDS_OPS_THR_ONLY
+#endif
 
 #include <errno.h>
 #include <algorithm>
@@ -495,10 +505,10 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
 extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_ms,
                                              float *backtrack_ms) {
   HIP_TRY(hipSetDevice(s->device));
-  /* the latency build keeps 2 workgroups per CU resident: beyond that, problems would queue
-   * behind each other and the throughput build (4 per CU) finishes the set sooner.
+  /* the latency build wants a CU per problem: beyond that, problems would queue behind each
+   * other and the throughput build (4 per CU) finishes the set sooner.
    * PEAKSEG_HIP_VARIANT=lat|thr overrides (tests, A/B runs). */
-  s->throughput = s->n_problems > 2 * s->n_cu;
+  s->throughput = s->n_problems > s->n_cu;
   if (const char *e = getenv("PEAKSEG_HIP_VARIANT")) {
     if (!strcmp(e, "lat")) s->throughput = false;
     if (!strcmp(e, "thr")) s->throughput = true;

@@ -263,7 +263,7 @@ def test_throughput_build_identical(psd, oracle_det, tmp_path, monkeypatch, n_bi
     monkeypatch.delenv("PEAKSEG_HIP_VARIANT", raising=False)
     auto = ProblemSet(contigs, problems)
     auto.solve()
-    want = "thr" if len(problems) > 512 else "lat"
+    want = "thr" if len(problems) > 256 else "lat"
     assert auto.kernel_build == want
     monkeypatch.setenv("PEAKSEG_HIP_VARIANT", "lat" if want == "thr" else "thr")
     other = ProblemSet(contigs, problems)
