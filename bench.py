@@ -8,8 +8,10 @@ rank solves its own contig x penalty grid (independent problems, weak scaling) a
 segment tables are gathered to rank 0 over RCCL inside the timed region.
 
 Prints ONE JSON line (rank 0): metric/value/unit per BASELINE.json, plus
-  roofline     -- forward kernel: algorithmic HBM bytes (24 B per (bin,penalty)
-                  + 20 B per stored piece) / HIP-event kernel time, against 8 TB/s
+  roofline     -- the kernel (forward pass with the decoding fused in): algorithmic HBM bytes
+                  (24 B per (bin,penalty) + 20 B per stored piece; decoding: per
+                  segment 12 B written, 8 B + 28 B per piece of the function read) / HIP-event
+                  kernel time, against 8 TB/s
   cpu_baseline -- the CPU oracle (libm build, disk-backed store like the reference) timed on
                   a bounded sample of the same workload on this host.
 """
@@ -155,6 +157,8 @@ def main():
         units = args.bins * args.penalties * world * args.steps
         total_pieces = sum(r.total_intervals for r in results)
         alg_bytes = 24.0 * args.bins * args.penalties + 20.0 * total_pieces
+        for r in results:  # decoding: one function looked up per segment
+            alg_bytes += r.n_segments * (20.0 + 28.0 * r.total_intervals / (2.0 * args.bins))
         fwd_s = float(np.mean(fwd)) / 1e3
         out = {
             "metric": "coverage bins/sec across 64-penalty grid",

@@ -22,4 +22,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace -d "$OUT/pmc_$c" -o pmc -- \
     python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu > "$OUT/pmc_$c.log" 2>&1 || exit 1
 done
-find "$OUT" -name "*.csv" | head -20
+# SQ counters of a 20k-bin run (what bounds the kernel: instruction mix, issue vs wait cycles)
+echo "== rocprofv3 --pmc SQ_* (20k bins)"
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS \
+  SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace -d "$OUT/pmc_sq1" -o pmc -- \
+  python3 "$REPO/bench.py" --bins 20000 --steps 1 --warmup 0 --no-cpu > "$OUT/pmc_sq1.log" 2>&1 || exit 1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_BRANCH \
+  SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS --kernel-trace \
+  -d "$OUT/pmc_sq2" -o pmc -- \
+  python3 "$REPO/bench.py" --bins 20000 --steps 1 --warmup 0 --no-cpu > "$OUT/pmc_sq2.log" 2>&1 || exit 1
+find "$OUT" -name "*.db" | head -20
