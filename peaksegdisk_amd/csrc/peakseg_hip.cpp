@@ -51,9 +51,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <map>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -775,25 +778,39 @@ void write_trivial(FileProblem &fp, const Coverage &cv) {
              0, 0, 0);
 }
 
-/* the DP branch's two files (drv:419-454) from the device results */
-int write_dp_outputs(FileProblem &fp, const Coverage &cv, psd_problem_set *set) {
-  psd_result r;
-  if (peakseg_hip_problem_set_result(set, fp.dp_index, &r) != 0 || r.status != 0)
-    return ERROR_DEVICE_SOLVER;
-  std::vector<int> seg_start((size_t)r.n_segments);
-  std::vector<double> seg_mean((size_t)r.n_segments);
-  if (peakseg_hip_problem_set_segments(set, fp.dp_index, r.n_segments, seg_start.data(),
-                                       seg_mean.data()) != r.n_segments)
-    return ERROR_DEVICE_SOLVER;
+/* one problem's results, copied off the device */
+struct DpFetched {
+  int status = 0;
+  psd_result r{};
+  std::vector<int> seg_start;
+  std::vector<double> seg_mean;
+};
+
+void fetch_dp(const FileProblem &fp, psd_problem_set *set, DpFetched &f) {
+  if (peakseg_hip_problem_set_result(set, fp.dp_index, &f.r) != 0 || f.r.status != 0) {
+    f.status = ERROR_DEVICE_SOLVER;
+    return;
+  }
+  f.seg_start.resize((size_t)f.r.n_segments);
+  f.seg_mean.resize((size_t)f.r.n_segments);
+  if (peakseg_hip_problem_set_segments(set, fp.dp_index, f.r.n_segments, f.seg_start.data(),
+                                       f.seg_mean.data()) != f.r.n_segments)
+    f.status = ERROR_DEVICE_SOLVER;
+}
+
+/* the DP branch's two files (drv:419-454) */
+int write_dp_outputs(FileProblem &fp, const Coverage &cv, const DpFetched &f) {
+  if (f.status) return f.status;
+  const psd_result &r = f.r;
   int prev_chromEnd = cv.chromEnd.back();
   const char *chrom = cv.chrom.c_str();
   for (int row = 0; row < r.n_segments; row++) {
-    int start = seg_start[(size_t)row] < 0 ? cv.first_chromStart
-                                           : cv.chromEnd[(size_t)seg_start[(size_t)row]];
+    int start = f.seg_start[(size_t)row] < 0 ? cv.first_chromStart
+                                             : cv.chromEnd[(size_t)f.seg_start[(size_t)row]];
     /* rows alternate background/peak starting and ending with background (drv:421-429,442) */
     const char *status_str = (row % 2 == 0) ? "background" : "peak";
     out_printf(fp.segments_file, fp.segments_failed, "%s\t%d\t%d\t%s\t%g\n", chrom, start,
-               prev_chromEnd, status_str, seg_mean[(size_t)row]);
+               prev_chromEnd, status_str, f.seg_mean[(size_t)row]);
     prev_chromEnd = start;
   }
   int n_peaks = (r.n_segments - 1) / 2;
@@ -810,7 +827,22 @@ int write_dp_outputs(FileProblem &fp, const Coverage &cv, psd_problem_set *set) 
   return 0;
 }
 
+double wall_now() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 int solve_files(int n, FileProblem *fps) {
+  /* PEAKSEG_HIP_TIMING=1: where a call spends its time, on stderr */
+  const bool timing = getenv("PEAKSEG_HIP_TIMING") != nullptr;
+  double t_mark = wall_now();
+  auto lap = [&](const char *what) {
+    if (!timing) return;
+    double now = wall_now();
+    fprintf(stderr, "peakseg_hip timing: %-28s %8.3f s\n", what, now - t_mark);
+    t_mark = now;
+  };
   std::vector<Coverage> covs;
   std::map<std::string, int> cov_of_path;
   std::map<std::string, int> cov_status;
@@ -833,6 +865,7 @@ int solve_files(int n, FileProblem *fps) {
     fp.cov = it->second;
     fp.status = cov_status[path];
   }
+  lap("parse bedGraph");
   /* 2. output files are opened before the trivial/DP split (drv:212-223); the db is only
    *    touched in the DP branch (drv:247-252) */
   std::vector<int> dp;
@@ -881,19 +914,42 @@ int solve_files(int n, FileProblem *fps) {
     int st = peakseg_hip_problem_set_create(0, (int)contig_n.size(), contig_n.data(),
                                             cnt_ptr.data(), wt_ptr.data(), (int)prob_contig.size(),
                                             prob_contig.data(), prob_pen.data(), 0, &set);
+    lap("upload + allocate");
     if (st == 0) {
       st = peakseg_hip_problem_set_solve(set, nullptr, nullptr);
       if (st == ERROR_DEVICE_SOLVER) st = 0; /* per-problem statuses decide below */
     }
-    for (int i : dp) {
-      FileProblem &fp = fps[i];
+    lap("kernel");
+    /* results leave the device one problem after the other; the text files (the segment
+     * tables of a penalty grid are hundreds of MB) are then formatted by a few threads */
+    std::vector<DpFetched> fetched(dp.size());
+    for (size_t k = 0; k < dp.size(); k++) {
       if (st) {
-        fp.status = st;
+        fetched[k].status = st;
       } else {
-        fp.status = write_dp_outputs(fp, covs[(size_t)fp.cov], set);
+        fetch_dp(fps[dp[k]], set, fetched[k]);
       }
     }
     peakseg_hip_problem_set_destroy(set);
+    lap("download results + free");
+    std::atomic<size_t> next_k{0};
+    auto writer = [&]() {
+      for (size_t k = next_k++; k < dp.size(); k = next_k++) {
+        FileProblem &fp = fps[dp[k]];
+        fp.status = write_dp_outputs(fp, covs[(size_t)fp.cov], fetched[k]);
+      }
+    };
+    unsigned n_threads = std::thread::hardware_concurrency();
+    if (n_threads > 16) n_threads = 16;
+    if (n_threads > dp.size()) n_threads = (unsigned)dp.size();
+    if (n_threads <= 1) {
+      writer();
+    } else {
+      std::vector<std::thread> pool;
+      for (unsigned w = 0; w < n_threads; w++) pool.emplace_back(writer);
+      for (auto &th : pool) th.join();
+    }
+    lap("write segments/loss files");
   }
   /* 4. close, report write failures (drv:456-461: loss first) */
   int first = 0;
