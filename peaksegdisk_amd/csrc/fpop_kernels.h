@@ -1,7 +1,8 @@
 /* fpop_kernels.h -- the HIP kernels of the PeakSegFPOP hot path.
  *
- *   fpop_forward_kernel   one workgroup of two wavefronts per (penalty, contig) problem:
- *                         wave 0 carries the "up" cost function, wave 1 the "down" one, through
+ *   fpop_forward_kernel   one workgroup per (penalty, contig) problem: wave 0 carries the "up"
+ *                         cost function, wave 1 the "down" one (waves 2 and 3, when
+ *                         PSD_HELPER_WAVES is defined, are their helpers, fpop_wave.h), through
  *                         the strictly sequential recurrence of
  *                         /root/reference/src/PeakSegFPOPLog.cpp:258-397 (one __syncthreads
  *                         per data point; the two updates of a step only read the previous

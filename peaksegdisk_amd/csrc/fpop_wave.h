@@ -24,8 +24,10 @@
  *     with the predecessor is equivalent); otherwise lane 0 replays the interval list
  *     sequentially (rare; counted in the stats).
  *
- * The three operations are out-of-line functions returning the piece count (>= 0) or
- * -(WERR_* bits): the fully inlined kernel was ~200 KB of code against a 64 KB I-cache.
+ * The three operations return the piece count (>= 0) or -(WERR_* bits).  Each exists as an
+ * inline body (*_impl) and an out-of-line wrapper (*_wave): inlining everything -- the LDS
+ * and the HBM instantiations, twice -- made a ~200 KB kernel against a 64 KB I-cache, so only
+ * the latency build inlines, and only the LDS instantiations (see the end of this file).
  */
 #include "fpop_pieces.h"
 #include "fpop_types.h"
