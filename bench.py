@@ -112,21 +112,19 @@ def main():
             dist.barrier()
 
     def one_step():
-        f_ms, b_ms = pset.solve()
+        f_ms, _ = pset.solve()
         tables = [pset.segments(p) for p in range(len(problems))]
         gathered = gather_segment_tables(tables, dist, device)
-        return f_ms, b_ms, gathered
+        return f_ms, gathered
 
     for _ in range(args.warmup):
         one_step()
     sync()
     t0 = time.time()
     fwd = []
-    bwd = []
     for _ in range(args.steps):
-        f_ms, b_ms, gathered = one_step()
+        f_ms, gathered = one_step()
         fwd.append(f_ms)
-        bwd.append(b_ms)
     sync()
     elapsed = time.time() - t0
     if dist is not None:
@@ -177,7 +175,7 @@ def main():
                 "workload": "%d-bin synthetic Poisson coverage x %d-penalty grid per GPU "
                             "(BASELINE.json configs[1])" % (args.bins, args.penalties),
                 "bins": args.bins, "penalties": args.penalties,
-                "penalty_grid": "10^seq(-1,5) %%.15g", "seed": "1+rank",
+                "penalty_grid": "10^seq(-1,5), 15 significant digits", "seed": "1+rank",
                 "sharding": "independent (contig x penalty) problems per rank; RCCL gather of "
                             "segment tables to rank 0",
             },
@@ -186,7 +184,7 @@ def main():
                 "achieved": alg_bytes / fwd_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": alg_bytes / fwd_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "kernel_ms": {"forward": float(np.mean(fwd)), "backtrack": float(np.mean(bwd))},
+                "kernel_ms": float(np.mean(fwd)),  # forward pass + decoding, one launch
                 "dp_steps_per_s_per_problem": args.bins / fwd_s,
                 "mean_intervals": total_pieces / (2.0 * args.bins * args.penalties),
             },
