@@ -73,6 +73,16 @@ struct ArenaCursor {
   int used, room;
 };
 
+/* Take the next run of arena chunks for this wave (cold: once per 65536 pieces).  Returns the
+ * first chunk index; ~0 when the arena is exhausted. */
+PSD_COLD_DEV unsigned long long arena_take_chunks(const DeviceArgs &a, int chunks) {
+  unsigned long long first = 0;
+  if (lane_id() == 0) first = atomicAdd(a.ar_next_chunk, (unsigned long long)chunks);
+  first = psd_d2u(rdlane_d(psd_u2d(first), 0));
+  if (((first + (unsigned long long)chunks) << ARENA_CHUNK_LOG2) > a.ar_cap) return ~0ull;
+  return first;
+}
+
 /* Append one function's backtrack record to the arena; returns false when it is full. */
 template <class L>
 PSD_D bool arena_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &f, int n,
@@ -80,13 +90,11 @@ PSD_D bool arena_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &f, i
   const int lane = lane_id();
   if (n > cur.room - cur.used) {
     int chunks = (n + ARENA_CHUNK - 1) >> ARENA_CHUNK_LOG2;
-    unsigned long long first = 0;
-    if (lane == 0) first = atomicAdd(a.ar_next_chunk, (unsigned long long)chunks);
-    first = psd_d2u(rdlane_d(psd_u2d(first), 0));
+    unsigned long long first = psd_d2u(uniform_d(psd_u2d(arena_take_chunks(a, chunks))));
+    if (first == ~0ull) return false;
     cur.base = first << ARENA_CHUNK_LOG2;
     cur.used = 0;
     cur.room = chunks << ARENA_CHUNK_LOG2;
-    if (cur.base + (unsigned long long)cur.room > a.ar_cap) return false;
   }
   unsigned long long off = cur.base + (unsigned long long)cur.used;
   for (int base = 0; base < n; base += WAVE) {
@@ -114,15 +122,14 @@ PSD_D bool scale_add_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &
   bool ok = true;
   if (store && n > cur.room - cur.used) {
     int chunks = (n + ARENA_CHUNK - 1) >> ARENA_CHUNK_LOG2;
-    unsigned long long first = 0;
-    if (lane == 0) first = atomicAdd(a.ar_next_chunk, (unsigned long long)chunks);
-    first = psd_d2u(rdlane_d(psd_u2d(first), 0));
-    cur.base = first << ARENA_CHUNK_LOG2;
-    cur.used = 0;
-    cur.room = chunks << ARENA_CHUNK_LOG2;
-    if (cur.base + (unsigned long long)cur.room > a.ar_cap) {
+    unsigned long long first = psd_d2u(uniform_d(psd_u2d(arena_take_chunks(a, chunks))));
+    if (first == ~0ull) {
       ok = false;
       store = false;
+    } else {
+      cur.base = first << ARENA_CHUNK_LOG2;
+      cur.used = 0;
+      cur.room = chunks << ARENA_CHUNK_LOG2;
     }
   }
   const unsigned long long off = cur.base + (unsigned long long)cur.used;
@@ -266,6 +273,38 @@ PSD_D int chain_step(const DeviceArgs &a, ArenaCursor &cur, unsigned long long f
   wave_sync();
   PSD_PROF_ADD(PROF_SCALE);
   return ok ? n_new : -WERR_ARENA;
+}
+
+/* Move one list between LDS and the HBM spill area (cold: only when a function outgrows LDS
+ * or has shrunk again). */
+PSD_COLD_DEV void move_list_hbm(const DeviceArgs &a, int p, int id, int n, int to_hbm) {
+  p = uniform_i(p);
+  id = uniform_i(id);
+  n = uniform_i(n);
+  if (uniform_i(to_hbm)) {
+    copy_list_across(lds_list(id), n, global_list(a, p, id));
+  } else {
+    copy_list_across(global_list(a, p, id), n, lds_list(id));
+  }
+}
+
+/* The same step with every list in the HBM spill area (functions that outgrew LDS): a cold,
+ * out-of-line function, so that its addressing does not hold registers in the kernel's loop. */
+PSD_COLD_DEV int chain_step_hbm(const DeviceArgs &a, ArenaCursor &cur,
+                                unsigned long long fn_index, int p, int chain, int t,
+                                int id_other_prev, int n_other, int id_own_prev, int n_own,
+                                int id_own_new, double pen_term, double cum_weight_prev, double w,
+                                int coverage, double cum_weight) {
+  p = uniform_i(p);
+  chain = uniform_i(chain);
+  t = uniform_i(t);
+  return chain_step<false>(a, cur, fn_index, chain, t,
+                           global_list(a, p, uniform_i(id_other_prev)), uniform_i(n_other),
+                           global_list(a, p, uniform_i(id_own_prev)), uniform_i(n_own),
+                           global_list(a, p, uniform_i(id_own_new)), global_list(a, p, 4 + chain),
+                           global_scratch(a, p, chain), a.spill_cap, uniform_d(pen_term),
+                           uniform_d(cum_weight_prev), uniform_d(w), uniform_i(coverage),
+                           uniform_d(cum_weight));
 }
 
 /* list ids: 2*chain + buffer for the two cost functions (chain 0 = up, 1 = down), 4 + chain
@@ -439,7 +478,7 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_OCC void fpop_forward_kernel(D
     const int n_other = uniform_i(g_sm.n[id_other_prev]);
     /* come back from HBM when both functions fit comfortably again */
     if (in_hbm && n_own <= LDS_CAP / 2 && n_other <= LDS_CAP / 2) {
-      copy_list_across(global_list(a, p, id_own_prev), n_own, lds_list(id_own_prev));
+      move_list_hbm(a, p, id_own_prev, n_own, 0);
       in_hbm = false;
       block_sync(chain);
     }
@@ -465,12 +504,12 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_OCC void fpop_forward_kernel(D
                            penalty / cum_weight_prev_i, cum_weight_prev_i, w, coverage,
                            cum_weight_new);
       } else {
-        n_new = chain_step<false>(a, cur, fn0 + (unsigned long long)t, chain, t,
-                           global_list(a, p, id_other_prev), n_other,
-                           global_list(a, p, id_own_prev), n_own, global_list(a, p, id_own_new),
-                           global_list(a, p, 4 + chain), global_scratch(a, p, chain),
-                           a.spill_cap, penalty / cum_weight_prev_i, cum_weight_prev_i, w,
-                           coverage, cum_weight_new);
+        ArenaCursor cur_hbm = cur; /* only this copy has its address taken */
+        n_new = chain_step_hbm(a, cur_hbm, fn0 + (unsigned long long)t, p, chain, t,
+                               id_other_prev, n_other, id_own_prev, n_own, id_own_new,
+                               penalty / cum_weight_prev_i, cum_weight_prev_i, w, coverage,
+                               cum_weight_new);
+        cur = cur_hbm;
       }
       /* ---- end of pass: report, store the backtrack record, meet the other wave ---- */
       PSD_PROF_T0();
@@ -496,7 +535,7 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_OCC void fpop_forward_kernel(D
       sync_no++;
       if (status == PST_LDS_OVERFLOW && !in_hbm && a.spill_cap > LDS_CAP && t > 0) {
         /* redo this data point with the lists in HBM: every wave moves its own t-1 list */
-        copy_list_across(lds_list(id_own_prev), n_own, global_list(a, p, id_own_prev));
+        move_list_hbm(a, p, id_own_prev, n_own, 1);
         in_hbm = true;
         status = 0;
         block_sync(chain);
