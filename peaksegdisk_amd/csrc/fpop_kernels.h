@@ -233,15 +233,17 @@ PSD_D int chain_step(const DeviceArgs &a, ArenaCursor &cur, unsigned long long f
 #else
   constexpr bool inline_ops = L::in_lds;
 #endif
+  /* inlined: the versions for functions of at most 64 (min_env: 32 + 32) pieces, i.e. nearly
+   * always; longer functions take the general out-of-line ones */
   if (chain == 0) {
-    if constexpr (inline_ops) {
-      nm = min_less_impl(other_prev, n_other, mlist, cap, sc, t - 1, pen_term);
+    if (inline_ops && n_other <= WAVE) {
+      nm = min_less_impl<true>(other_prev, n_other, mlist, cap, sc, t - 1, pen_term);
     } else {
       nm = min_less_wave(other_prev, n_other, mlist, cap, sc, t - 1, pen_term);
     }
   } else if (t >= 2) {
-    if constexpr (inline_ops) {
-      nm = min_more_impl(other_prev, n_other, mlist, cap, sc, t - 1);
+    if (inline_ops && n_other <= WAVE) {
+      nm = min_more_impl<true>(other_prev, n_other, mlist, cap, sc, t - 1);
     } else {
       nm = min_more_wave(other_prev, n_other, mlist, cap, sc, t - 1);
     }
@@ -259,8 +261,9 @@ PSD_D int chain_step(const DeviceArgs &a, ArenaCursor &cur, unsigned long long f
     }
   } else {
     const L f1 = chain == 0 ? mlist : mlist.shifted(cap - nm);
-    if constexpr (inline_ops) {
-      n_new = uniform_i(min_env_impl<HELP>(f1, nm, own_prev, n_own, own_new, cap, sc, chain));
+    if (inline_ops && nm <= 32 && n_own <= 32) {
+      n_new =
+          uniform_i(min_env_impl<HELP, true>(f1, nm, own_prev, n_own, own_new, cap, sc, chain));
     } else {
       n_new = uniform_i(min_env_wave<HELP>(f1, nm, own_prev, n_own, own_new, cap, sc, chain));
     }

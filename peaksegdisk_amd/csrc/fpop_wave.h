@@ -395,7 +395,7 @@ PSD_D void piece_costs_wave(const L &in, int n, const S &s, LanePiece &P) {
 /* min-less: out(x) = min_{y<=x} in(y).  All output pieces get data_i = data_i_out (the
  * driver's set_prev_seg_end) and Constant += add_const (its add(0,0,penalty/cum_weight_prev),
  * PeakSegFPOPLog.cpp:290-296). */
-template <class L, class S>
+template <bool SMALL, class L, class S>
 PSD_D int min_less_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
                         double add_const_) {
   const L in = in_.uniformed(), out = out_.uniformed();
@@ -403,7 +403,9 @@ PSD_D int min_less_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
   const int n = uniform_i(n_), cap = uniform_i(cap_), data_i_out = uniform_i(data_i_out_);
   const double add_const = uniform_d(add_const_);
   const int lane = lane_id();
-  const bool small = n <= WAVE; /* lane i holds piece i */
+  /* lane i holds piece i; SMALL: the caller guarantees n <= WAVE (the other code drops out) */
+  if (SMALL) PSD_ASSUME(n <= WAVE);
+  const bool small = SMALL || n <= WAVE;
   LanePiece P;
   P.c.Linear = P.c.Log = P.c.Constant = 0.0;
   P.mn = P.mx = P.lc = P.rc = P.om = P.mu = P.muc = P.oc2 = 0.0;
@@ -726,13 +728,14 @@ PSD_D int min_less_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
 /* ------------------------------------------------------------------------------------- */
 /* min-more: out(x) = min_{y>=x} in(y).  The reference builds the list with emplace_front;
  * here pieces are written downwards from out[cap-1]: the result is out[cap-n .. cap). */
-template <class L, class S>
+template <bool SMALL, class L, class S>
 PSD_D int min_more_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_) {
   const L in = in_.uniformed(), out = out_.uniformed();
   const S s = s_.uniformed();
   const int n = uniform_i(n_), cap = uniform_i(cap_), data_i_out = uniform_i(data_i_out_);
   const int lane = lane_id();
-  const bool small = n <= WAVE;
+  if (SMALL) PSD_ASSUME(n <= WAVE);
+  const bool small = SMALL || n <= WAVE;
   LanePiece P;
   P.c.Linear = P.c.Log = P.c.Constant = 0.0;
   P.mn = P.mx = P.lc = P.rc = P.om = P.mu = P.muc = P.oc2 = 0.0;
@@ -1644,7 +1647,7 @@ PSD_NOINLINE int min_env_serial(L f1_, int n1_, L f2_, int n2_, L out_, int cap_
 }
 
 /* min-envelope: out = pointwise min(f1, f2). */
-template <bool HELP, class L, class S>
+template <bool HELP, bool SMALL, class L, class S>
 PSD_D int min_env_impl(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, int chain_) {
   const int chain = uniform_i(chain_);
   const L f1 = f1_.uniformed(), f2 = f2_.uniformed(), out = out_.uniformed();
@@ -1652,10 +1655,11 @@ PSD_D int min_env_impl(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, i
   const int n1 = uniform_i(n1_), n2 = uniform_i(n2_), cap = uniform_i(cap_);
   const int lane = lane_id();
   const int iv_cap = s.iv_cap();
+  if (SMALL) PSD_ASSUME(n1 <= 32 && n2 <= 32);
   PSD_PROF_T0();
   /* ---- merged-interval table: interval k ends at the k-th distinct max_log_mean ---- */
   int K;
-  if (n1 <= 32 && n2 <= 32) {
+  if (SMALL || (n1 <= 32 && n2 <= 32)) { /* SMALL: guaranteed by the caller */
     /* both lists in one pass: lanes 0-31 rank the ends of f1 in f2, lanes 32-63 those of f2
      * in f1 (the usual case: one ballot, one pass of broadcast reads) */
     const int side = lane >> 5, idx = lane & 31;
@@ -1849,6 +1853,7 @@ PSD_D int min_env_impl(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, i
     n_out += heads_total;
     if (m_has) last_id = rdlane_i(my_last_id, msb64(m_has));
     PSD_PROF_ADD(PROF_COMPACT);
+    if (SMALL) break; /* K <= 64: one chunk */
   }
   if (need_serial) {
     if (lane == 0) g_sm.serial[wave_id()]++;
@@ -1865,15 +1870,15 @@ PSD_D int min_env_impl(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, i
 template <class L, class S>
 PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
                                double add_const) {
-  return min_less_impl(in, n, out, cap, s, data_i_out, add_const);
+  return min_less_impl<false>(in, n, out, cap, s, data_i_out, add_const);
 }
 template <class L, class S>
 PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, S s, int data_i_out) {
-  return min_more_impl(in, n, out, cap, s, data_i_out);
+  return min_more_impl<false>(in, n, out, cap, s, data_i_out);
 }
 template <bool HELP, class L, class S>
 PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap, S s, int chain) {
-  return min_env_impl<HELP>(f1, n1, f2, n2, out, cap, s, chain);
+  return min_env_impl<HELP, false>(f1, n1, f2, n2, out, cap, s, chain);
 }
 
 

@@ -42,6 +42,15 @@
 #define PSD_COLD_DEV __device__ __attribute__((noinline, cold))
 #endif
 
+#if defined(__clang__)
+#define PSD_ASSUME(x) __builtin_assume(x)
+#else
+#define PSD_ASSUME(x)           \
+  do {                          \
+    if (!(x)) __builtin_unreachable(); \
+  } while (0)
+#endif
+
 #include "peakseg_detmath.h"
 
 namespace psd {
