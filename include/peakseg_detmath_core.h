@@ -1,0 +1,89 @@
+/* peakseg_detmath_core.h -- the bodies of psd_exp / psd_log.
+ *
+ * NO include guard.  peakseg_detmath.h includes this file with PSD_FN(name) = name and
+ * PSD_K(x) = x: the functions every host program and the oracle use.  Device code gets a second
+ * set, name##_vk, whose fp64 constants are held in vector registers (PSD_K = psd_vk): as
+ * literals they live in scalar register pairs for the whole kernel (24 SGPRs), and the
+ * latency build of the forward kernel is short of SGPRs -- every spilled SGPR costs a
+ * v_readlane at each use -- while the throughput build is short of VGPRs and keeps the
+ * plain set.  Same source text, same operations in the same order: same bits.
+ */
+
+/* Core of exp: x = (128 k + j) ln2/128 + r, |r| <= ln2/256,
+ * exp(x) = 2^k * T[j] * (1 + p(r)),  p = r + r^2/2 + ... + r^5/120  (truncation 5e-19).
+ * Returns t = tail_j + p(r) and hi_j; *kq = 128 k + j. */
+PSD_HD static inline double PSD_FN(psd_exp_core)(double x, long long *kq, double *hi) {
+  const double shift = PSD_K(0x1.8p52);
+  double z = x * PSD_K(PSD_INV_LN2N) + shift; /* low mantissa bits = rint(x * 128/ln2) */
+  long long ki = (long long)psd_d2u(z) - (long long)0x4338000000000000LL;
+  double kd = z - shift;
+  double r = psd_fma(kd, PSD_K(-PSD_LN2N_HI), x);
+  r = psd_fma(kd, PSD_K(-PSD_LN2N_LO), r);
+  int j = (int)(ki & (PSD_EXP_N - 1));
+  double tail = PSD_T_EXP(2 * j);
+  *hi = PSD_T_EXP(2 * j + 1);
+  *kq = ki;
+  double r2 = r * r;
+  double a = psd_fma(r, PSD_K(0x1.5555555555555p-3), 0.5); /* 1/2 + r/6 */
+  double b = psd_fma(r, PSD_K(0x1.1111111111111p-7), PSD_K(0x1.5555555555555p-5)); /* 1/24 + r/120 */
+  double t = tail + r;
+  t = psd_fma(r2, a, t);
+  return psd_fma(r2 * r2, b, t);
+}
+
+/* exp(x); |x| <= 708 keeps the result normal.  The hot path is computed unconditionally (it
+ * is harmless for any argument: the table index is masked) and replaced for the rare lanes
+ * that need psd_exp_slow. */
+PSD_HD static inline double PSD_FN(psd_exp)(double x) {
+  long long kq;
+  double hi;
+  double t = PSD_FN(psd_exp_core)(x, &kq, &hi);
+  /* scale = 2^k * hi_j: add k to the exponent field */
+  double scale = psd_u2d(psd_d2u(hi) + ((uint64_t)(kq >> 7) << 52));
+  double y = psd_fma(scale, t, scale);
+  const int rare = !(__builtin_fabs(x) <= 708.0);
+  if (PSD_ANY_LANE(rare)) {
+    if (rare) y = psd_exp_slow(x);
+  }
+  return y;
+}
+
+/* log of a positive normal number given its bits; k0 = exponent adjustment.
+ * x = 2^k m, m in [1,2); c = 1 + J/128 is the table point nearest to m (J = 0..128),
+ * r = m * invc - 1 (|r| <= 2^-8, exact for J = 0 and J = 128),
+ * log x = k ln2 + (-log invc) + log1p(r),  log1p(r) = r + r^2 q(r), q of degree 5.
+ * k*LN2_HI + logc_hi is exact by construction of the table, the rest is accumulated in a
+ * low word.  For x near 1 (J = 0 with k = 0, or J = 128 with k = -1) the table terms cancel
+ * exactly and the result keeps full relative accuracy. */
+PSD_HD static inline double PSD_FN(psd_log_core)(uint64_t hx, int k0) {
+  int k = k0 + (int)(hx >> 52) - 1023;
+  uint64_t mant = hx & 0x000fffffffffffffULL;
+  int J = (int)((mant + 0x0000100000000000ULL) >> 45);
+  double m = psd_u2d(mant | 0x3ff0000000000000ULL);
+  double invc = PSD_T_INVC(J);
+  double logc_hi = PSD_T_LOGC_HI(J);
+  double logc_lo = PSD_T_LOGC_LO(J);
+  double r = psd_fma(m, invc, -1.0);
+  double kd = (double)k;
+  double w = psd_fma(kd, PSD_K(PSD_LN2_HI), logc_hi); /* exact */
+  double hi = w + r;
+  double lo = (w - hi) + r; /* exact: w == 0 or |w| > |r| */
+  lo = lo + psd_fma(kd, PSD_K(PSD_LN2_LO), logc_lo);
+  double r2 = r * r;
+  double q01 = psd_fma(r, PSD_K(0x1.5555555555555p-2), -0.5);  /* -1/2 + r/3 */
+  double q23 = psd_fma(r, PSD_K(0x1.999999999999ap-3), -0.25); /* -1/4 + r/5 */
+  double q45 = psd_fma(r, PSD_K(0x1.2492492492492p-3), PSD_K(-0x1.5555555555555p-3)); /* -1/6 + r/7 */
+  double q = psd_fma(r2 * r2, q45, psd_fma(r2, q23, q01));
+  return psd_fma(r2, q, lo) + hi;
+}
+
+PSD_HD static inline double PSD_FN(psd_log)(double x) {
+  uint64_t hx = psd_d2u(x);
+  double y = PSD_FN(psd_log_core)(hx, 0);
+  /* anything but positive, normal, finite: one unsigned compare */
+  const int rare = !(hx - 0x0010000000000000ULL < 0x7fe0000000000000ULL);
+  if (PSD_ANY_LANE(rare)) {
+    if (rare) y = psd_log_slow(x);
+  }
+  return y;
+}

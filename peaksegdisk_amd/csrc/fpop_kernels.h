@@ -238,12 +238,16 @@ PSD_D int chain_step(const DeviceArgs &a, ArenaCursor &cur, unsigned long long f
   if (chain == 0) {
     if (inline_ops && n_other <= WAVE) {
       nm = min_less_impl<true>(other_prev, n_other, mlist, cap, sc, t - 1, pen_term);
+    } else if (L::in_lds && n_other <= WAVE) {
+      nm = min_less_small_wave(other_prev, n_other, mlist, cap, sc, t - 1, pen_term);
     } else {
       nm = min_less_wave(other_prev, n_other, mlist, cap, sc, t - 1, pen_term);
     }
   } else if (t >= 2) {
     if (inline_ops && n_other <= WAVE) {
       nm = min_more_impl<true>(other_prev, n_other, mlist, cap, sc, t - 1);
+    } else if (L::in_lds && n_other <= WAVE) {
+      nm = min_more_small_wave(other_prev, n_other, mlist, cap, sc, t - 1);
     } else {
       nm = min_more_wave(other_prev, n_other, mlist, cap, sc, t - 1);
     }
@@ -264,6 +268,9 @@ PSD_D int chain_step(const DeviceArgs &a, ArenaCursor &cur, unsigned long long f
     if (inline_ops && nm <= 32 && n_own <= 32) {
       n_new =
           uniform_i(min_env_impl<HELP, true>(f1, nm, own_prev, n_own, own_new, cap, sc, chain));
+    } else if (L::in_lds && nm <= 32 && n_own <= 32) {
+      n_new = uniform_i(
+          min_env_small_wave<HELP>(f1, nm, own_prev, n_own, own_new, cap, sc, chain));
     } else {
       n_new = uniform_i(min_env_wave<HELP>(f1, nm, own_prev, n_own, own_new, cap, sc, chain));
     }
@@ -406,7 +413,17 @@ constexpr int FORWARD_THREADS = 128;
 PSD_D void block_sync(int) { __syncthreads(); }
 #endif
 
-__global__ __launch_bounds__(FORWARD_THREADS) PSD_OCC void fpop_forward_kernel(DeviceArgs a) {
+/* PSD_KERNEL_WAVES_PER_EU (throughput build): keep the kernel's own register use within the
+ * budget of that many waves per SIMD, as the out-of-line operations already are */
+#undef PSD_KERNEL_OCC
+#if defined(PSD_KERNEL_WAVES_PER_EU) && !defined(PSD_EMU)
+#define PSD_KERNEL_OCC \
+  __attribute__((amdgpu_waves_per_eu(PSD_KERNEL_WAVES_PER_EU, PSD_KERNEL_WAVES_PER_EU)))
+#else
+#define PSD_KERNEL_OCC
+#endif
+__global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_kernel(
+    DeviceArgs a) {
   const int p = a.prob_order[blockIdx.x];
   const int chain = uniform_i(wave_id()) & 1; /* uniform per wave: say so (scalar branches) */
   const int lane = lane_id();

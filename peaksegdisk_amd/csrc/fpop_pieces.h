@@ -6,17 +6,21 @@
  * and operand order are the reference's: they decide the rounding of every fp64 result and
  * therefore every branch of the piece-list algebra.  exp/log are the deterministic pair of
  * include/peakseg_detmath.h; the file is compiled with -ffp-contract=off.
- */
-#ifndef PSD_FPOP_PIECES_H
-#define PSD_FPOP_PIECES_H
-
+ *
+ * NO include guard: compiled once per build variant into namespace psd::PSD_VARIANT (see
+ * fpop_wave.h); PSD_MATH_VK selects the exp/log pair with constants in vector registers. */
 #include "psd_platform.h"
+
+#ifndef PSD_VARIANT
+#error "define PSD_VARIANT before including fpop_pieces.h (see fpop_wave.h)"
+#endif
 
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
 
 namespace psd {
+namespace PSD_VARIANT {
 
 constexpr double NEWTON_EPSILON = 1e-12; /* fpl:9 */
 #ifdef PSD_NEWTON_STEPS /* tests only: force the step-cap fallback of the root finders */
@@ -36,8 +40,13 @@ PSD_D double absd(double x) { return x < 0 ? -x : x; } /* fpl:13 ABS */
 /* Leaf math stays inline: an out-of-line exp/log/root makes every caller spill its live
  * doubles to scratch around the call.  Code size is controlled one level up instead (the
  * wave operations of fpop_wave.h are the out-of-line units). */
+#if defined(PSD_MATH_VK) && defined(__HIP_DEVICE_COMPILE__)
+PSD_D double d_exp(double x) { return psd_exp_vk(x); }
+PSD_D double d_log(double x) { return psd_log_vk(x); }
+#else
 PSD_D double d_exp(double x) { return psd_exp(x); }
 PSD_D double d_log(double x) { return psd_log(x); }
+#endif
 
 /* fpl:192-197 */
 PSD_D double argmin_mean(const Coef &c) { return -c.Log / c.Linear; }
@@ -251,5 +260,5 @@ PSD_D bool same_funs(const Coef &a, const Coef &b) {
          absd(a.Constant - b.Constant) < NEWTON_EPSILON;
 }
 
+}  // namespace PSD_VARIANT
 }  // namespace psd
-#endif

@@ -29,17 +29,18 @@
  * and the HBM instantiations, twice -- made a ~200 KB kernel against a 64 KB I-cache, so only
  * the latency build inlines, and only the LDS instantiations (see the end of this file).
  */
-#include "fpop_pieces.h"
 #include "fpop_types.h"
 
 /* NO include guard: everything below is compiled once per build variant, into namespace
  * psd::PSD_VARIANT.  The includer defines
  *   PSD_VARIANT       namespace of this variant (lat, thr)
  *   PSD_LDS_CAP       pieces per LDS-resident list
- *   PSD_HELPER_WAVES  defined: 4 waves per workgroup (two chains + their helper waves) */
+ *   PSD_HELPER_WAVES  defined: 4 waves per workgroup (two chains + their helper waves)
+ *   PSD_MATH_VK       defined: exp/log with their constants in vector registers */
 #if !defined(PSD_VARIANT) || !defined(PSD_LDS_CAP)
 #error "define PSD_VARIANT and PSD_LDS_CAP before including fpop_wave.h / fpop_kernels.h"
 #endif
+#include "fpop_pieces.h"
 
 #if defined(__clang__)
 #pragma clang fp contract(off)
@@ -1880,7 +1881,21 @@ template <bool HELP, class L, class S>
 PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap, S s, int chain) {
   return min_env_impl<HELP, false>(f1, n1, f2, n2, out, cap, s, chain);
 }
-
+/* the same, specialised for n <= 64 (min_env: n1, n2 <= 32): what the throughput build, whose
+ * operations all stay out of line, calls for nearly every data point */
+template <class L, class S>
+PSD_NOINLINE int min_less_small_wave(L in, int n, L out, int cap, S s, int data_i_out,
+                                     double add_const) {
+  return min_less_impl<true>(in, n, out, cap, s, data_i_out, add_const);
+}
+template <class L, class S>
+PSD_NOINLINE int min_more_small_wave(L in, int n, L out, int cap, S s, int data_i_out) {
+  return min_more_impl<true>(in, n, out, cap, s, data_i_out);
+}
+template <bool HELP, class L, class S>
+PSD_NOINLINE int min_env_small_wave(L f1, int n1, L f2, int n2, L out, int cap, S s, int chain) {
+  return min_env_impl<HELP, true>(f1, n1, f2, n2, out, cap, s, chain);
+}
 
 }  // namespace PSD_VARIANT
 }  // namespace psd

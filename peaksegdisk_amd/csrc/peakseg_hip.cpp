@@ -23,6 +23,7 @@
  * Both produce identical results. */
 #define PSD_VARIANT lat
 #define PSD_LDS_CAP 128
+#define PSD_MATH_VK 1
 #ifndef PSD_NO_HELPER_WAVES /* -DPSD_NO_HELPER_WAVES: A/B builds (tools/ab_libs.py) */
 #define PSD_HELPER_WAVES 1
 #endif
@@ -30,8 +31,10 @@
 #undef PSD_VARIANT
 #undef PSD_LDS_CAP
 #undef PSD_HELPER_WAVES
+#undef PSD_MATH_VK
 #define PSD_VARIANT thr
 #define PSD_LDS_CAP 64
+#define PSD_KERNEL_WAVES_PER_EU 2
 #ifndef PSD_CALL_LDS_OPS
 #define PSD_CALL_LDS_OPS 1
 #define PSD_CALL_LDS_OPS_THR_ONLY 1
@@ -39,6 +42,7 @@
 #include "fpop_kernels.h"
 #undef PSD_VARIANT
 #undef PSD_LDS_CAP
+#undef PSD_KERNEL_WAVES_PER_EU
 #ifdef PSD_CALL_LDS_OPS_THR_ONLY
 #undef PSD_CALL_LDS_OPS
 #undef PSD_CALL_LDS_OPS_THR_ONLY

@@ -20,7 +20,6 @@
 #define PSD_M inline
 #define PSD_NOINLINE static __attribute__((noinline))
 #define PSD_LDS static
-#define PSD_OCC
 #define PSD_COLD_DEV static __attribute__((noinline, cold))
 #else
 #include <hip/hip_runtime.h>
@@ -28,11 +27,6 @@
 #define PSD_M __device__ __forceinline__
 /* out-of-line device functions: keeps the forward kernel's hot loop inside the 64 KB
  * instruction cache (fully inlined it was ~200 KB) */
-#ifdef PSD_WAVES_PER_EU /* experiment: cap registers so that this many waves fit one SIMD */
-#define PSD_OCC __attribute__((amdgpu_waves_per_eu(PSD_WAVES_PER_EU, PSD_WAVES_PER_EU)))
-#else
-#define PSD_OCC
-#endif
 #ifdef PSD_INLINE_WAVE_OPS /* experiment: everything inlined into the kernel */
 #define PSD_NOINLINE __device__ __forceinline__
 #else

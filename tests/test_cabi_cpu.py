@@ -207,3 +207,36 @@ def test_fast_parser_equals_sscanf(native, tmp_path):
     open(str(tmp_path / "empty"), "w").write("")
     assert probe(str(tmp_path / "empty"), 1) == probe(str(tmp_path / "empty"), 0)
     assert probe(str(tmp_path / "empty"), 1)[0] == 9
+
+
+def test_kernel_resource_budgets(tmp_path):
+    """The two builds of the forward kernel are defined by their occupancy:
+    the throughput build must fit 2 waves per SIMD and 4 workgroups per CU (<= 40 KB LDS) --
+    a register or LDS regression silently halves its throughput -- and the latency build must
+    fit one workgroup of 4 waves.  Checked on the compiler's resource remarks (no GPU needed)."""
+    import re
+    import subprocess
+    import __graft_entry__ as entry
+    csrc = os.path.join(ROOT, "peaksegdisk_amd", "csrc")
+    out = subprocess.run(
+        [entry.HIPCC, "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17",
+         "-ffp-contract=off", "-fPIC", "-shared", "-Rpass-analysis=kernel-resource-usage",
+         "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+         os.path.join(csrc, "peakseg_hip.cpp"), "-o", str(tmp_path / "lib.so")],
+        capture_output=True, text=True, check=True).stderr
+    info = {}
+    name = None
+    for line in out.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            info[name] = {}
+        for key in ("Occupancy [waves/SIMD]", "LDS Size [bytes/block]"):
+            m = re.search(re.escape(key) + r": (\d+)", line)
+            if m and name:
+                info[name][key] = int(m.group(1))
+    thr = next(v for k, v in info.items() if "3thr19fpop_forward_kernel" in k)
+    lat = next(v for k, v in info.items() if "3lat19fpop_forward_kernel" in k)
+    assert thr["Occupancy [waves/SIMD]"] >= 2, thr
+    assert thr["LDS Size [bytes/block]"] <= 40 * 1024, thr
+    assert lat["Occupancy [waves/SIMD]"] >= 1 and lat["LDS Size [bytes/block]"] <= 160 * 1024, lat
