@@ -228,25 +228,16 @@ PSD_D int chain_step(const DeviceArgs &a, ArenaCursor &cur, unsigned long long f
                      double pen_term, double cum_weight_prev, double w, int coverage,
                      double cum_weight) {
   int nm = 0;
-#ifdef PSD_CALL_LDS_OPS /* A/B: the LDS instantiations out of line as well */
-  constexpr bool inline_ops = false;
-#else
-  constexpr bool inline_ops = L::in_lds;
-#endif
-  /* inlined: the versions for functions of at most 64 (min_env: 32 + 32) pieces, i.e. nearly
-   * always; longer functions take the general out-of-line ones */
+  /* operations out of line; in LDS the versions specialised for short functions when they
+   * apply */
   if (chain == 0) {
-    if (inline_ops && n_other <= WAVE) {
-      nm = min_less_impl<true>(other_prev, n_other, mlist, cap, sc, t - 1, pen_term);
-    } else if (L::in_lds && n_other <= WAVE) {
+    if (L::in_lds && n_other <= WAVE) {
       nm = min_less_small_wave(other_prev, n_other, mlist, cap, sc, t - 1, pen_term);
     } else {
       nm = min_less_wave(other_prev, n_other, mlist, cap, sc, t - 1, pen_term);
     }
   } else if (t >= 2) {
-    if (inline_ops && n_other <= WAVE) {
-      nm = min_more_impl<true>(other_prev, n_other, mlist, cap, sc, t - 1);
-    } else if (L::in_lds && n_other <= WAVE) {
+    if (L::in_lds && n_other <= WAVE) {
       nm = min_more_small_wave(other_prev, n_other, mlist, cap, sc, t - 1);
     } else {
       nm = min_more_wave(other_prev, n_other, mlist, cap, sc, t - 1);
@@ -265,16 +256,45 @@ PSD_D int chain_step(const DeviceArgs &a, ArenaCursor &cur, unsigned long long f
     }
   } else {
     const L f1 = chain == 0 ? mlist : mlist.shifted(cap - nm);
-    if (inline_ops && nm <= 32 && n_own <= 32) {
-      n_new =
-          uniform_i(min_env_impl<HELP, true>(f1, nm, own_prev, n_own, own_new, cap, sc, chain));
-    } else if (L::in_lds && nm <= 32 && n_own <= 32) {
+    if (L::in_lds && nm <= 32 && n_own <= 32) {
       n_new = uniform_i(
           min_env_small_wave<HELP>(f1, nm, own_prev, n_own, own_new, cap, sc, chain));
     } else {
       n_new = uniform_i(min_env_wave<HELP>(f1, nm, own_prev, n_own, own_new, cap, sc, chain));
     }
   }
+  if (n_new < 0) return n_new;
+  PSD_PROF_T0();
+  wave_sync();
+  bool ok = scale_add_store_wave(a, cur, own_new, n_new, fn_index, true, cum_weight_prev, w,
+                                 (double)(-coverage) * w, 1 / cum_weight);
+  wave_sync();
+  PSD_PROF_ADD(PROF_SCALE);
+  return ok ? n_new : -WERR_ARENA;
+}
+
+/* The same update for the usual case -- data point t >= 2, lists in LDS, n_other <= 16 (so
+ * that the min-less / min-more result has at most 32 pieces) and n_own <= 32 -- with the
+ * specialised operations inlined and not a single call: what the latency build runs for
+ * nearly every data point. */
+constexpr int FAST_MAX_OTHER = 16, FAST_MAX_OWN = 32;
+template <bool HELP>
+PSD_D int chain_step_fast(const DeviceArgs &a, ArenaCursor &cur, unsigned long long fn_index,
+                          int chain, int t, const LdsList &other_prev, int n_other,
+                          const LdsList &own_prev, int n_own, const LdsList &own_new,
+                          const LdsList &mlist, const LdsScratch &sc, double pen_term,
+                          double cum_weight_prev, double w, int coverage, double cum_weight) {
+  PSD_ASSUME(n_other <= FAST_MAX_OTHER && n_own <= FAST_MAX_OWN);
+  int nm;
+  if (chain == 0) {
+    nm = min_less_impl<true>(other_prev, n_other, mlist, LDS_CAP, sc, t - 1, pen_term);
+  } else {
+    nm = min_more_impl<true>(other_prev, n_other, mlist, LDS_CAP, sc, t - 1);
+  }
+  if (nm < 0) return nm;
+  if (nm > 32) return -WERR_OVERFLOW; /* cannot happen: at most 2 pieces per input piece */
+  const LdsList f1 = chain == 0 ? mlist : mlist.shifted(LDS_CAP - nm);
+  int n_new = min_env_impl<HELP, true>(f1, nm, own_prev, n_own, own_new, LDS_CAP, sc, chain);
   if (n_new < 0) return n_new;
   PSD_PROF_T0();
   wave_sync();
@@ -296,6 +316,24 @@ PSD_COLD_DEV void move_list_hbm(const DeviceArgs &a, int p, int id, int n, int t
   } else {
     copy_list_across(global_list(a, p, id), n, lds_list(id));
   }
+}
+
+/* The general LDS step as one out-of-line function (latency build: data point 1 and functions
+ * longer than chain_step_fast takes). */
+template <bool HELP>
+PSD_COLD_DEV int chain_step_lds(const DeviceArgs &a, ArenaCursor &cur, unsigned long long fn_index,
+                                int chain, int t, int id_other_prev, int n_other, int id_own_prev,
+                                int n_own, int id_own_new, double pen_term, double cum_weight_prev,
+                                double w, int coverage, double cum_weight) {
+  chain = uniform_i(chain);
+  t = uniform_i(t);
+  LdsScratch lsc;
+  lsc.w = chain;
+  return chain_step<HELP>(a, cur, fn_index, chain, t, lds_list(uniform_i(id_other_prev)),
+                          uniform_i(n_other), lds_list(uniform_i(id_own_prev)), uniform_i(n_own),
+                          lds_list(uniform_i(id_own_new)), lds_list(4 + chain), lsc, LDS_CAP,
+                          uniform_d(pen_term), uniform_d(cum_weight_prev), uniform_d(w),
+                          uniform_i(coverage), uniform_d(cum_weight));
 }
 
 /* The same step with every list in the HBM spill area (functions that outgrew LDS): a cold,
@@ -518,11 +556,27 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
           n_new = 1;
         }
       } else if (!in_hbm) {
+#ifdef PSD_CALL_LDS_OPS /* throughput build: operations out of line (register budget) */
         n_new = chain_step<USE_HELPER>(a, cur, fn0 + (unsigned long long)t, chain, t,
                            lds_list(id_other_prev), n_other, lds_list(id_own_prev),
                            n_own, lds_list(id_own_new), mlist, lsc, LDS_CAP,
                            penalty / cum_weight_prev_i, cum_weight_prev_i, w, coverage,
                            cum_weight_new);
+#else
+        if (t >= 2 && n_other <= FAST_MAX_OTHER && n_own <= FAST_MAX_OWN) {
+          n_new = chain_step_fast<USE_HELPER>(
+              a, cur, fn0 + (unsigned long long)t, chain, t, lds_list(id_other_prev), n_other,
+              lds_list(id_own_prev), n_own, lds_list(id_own_new), mlist, lsc,
+              penalty / cum_weight_prev_i, cum_weight_prev_i, w, coverage, cum_weight_new);
+        } else {
+          ArenaCursor cur_gen = cur; /* only this copy has its address taken */
+          n_new = chain_step_lds<USE_HELPER>(
+              a, cur_gen, fn0 + (unsigned long long)t, chain, t, id_other_prev, n_other,
+              id_own_prev, n_own, id_own_new, penalty / cum_weight_prev_i, cum_weight_prev_i, w,
+              coverage, cum_weight_new);
+          cur = cur_gen;
+        }
+#endif
       } else {
         ArenaCursor cur_hbm = cur; /* only this copy has its address taken */
         n_new = chain_step_hbm(a, cur_hbm, fn0 + (unsigned long long)t, p, chain, t,
