@@ -336,6 +336,27 @@ PSD_COLD_DEV int chain_step_lds(const DeviceArgs &a, ArenaCursor &cur, unsigned 
                           uniform_i(coverage), uniform_d(cum_weight));
 }
 
+/* Data point 0 (cold, once per problem): C^down_1 = gamma_1 / w_1 (drv:266-270), stored
+ * unscaled (drv:391); there is no up function yet.  Returns the piece count of the chain's
+ * function or -WERR_ARENA. */
+PSD_COLD_DEV int first_point(const DeviceArgs &a, ArenaCursor &cur, unsigned long long fn0,
+                             int chain, int contig, int coverage, int id_own_new) {
+  chain = uniform_i(chain);
+  if (chain != 1) return 0;
+  const LdsList own_new = lds_list(uniform_i(id_own_new));
+  contig = uniform_i(contig);
+  if (lane_id() == 0) {
+    Coef c;
+    c.Linear = 1.0;
+    c.Log = (double)(-uniform_i(coverage));
+    c.Constant = 0.0;
+    store_piece(own_new, 0, c, a.contig_min_log_mean[contig], a.contig_max_log_mean[contig], -1,
+                -5.0);
+  }
+  wave_sync();
+  return arena_store_wave(a, cur, own_new, 1, fn0) ? 1 : -WERR_ARENA;
+}
+
 /* The same step with every list in the HBM spill area (functions that outgrew LDS): a cold,
  * out-of-line function, so that its addressing does not hold registers in the kernel's loop. */
 PSD_COLD_DEV int chain_step_hbm(const DeviceArgs &a, ArenaCursor &cur,
@@ -543,18 +564,9 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
     int n_new = 0;
     for (;;) { /* at most two passes: LDS, then HBM after an overflow */
       if (t == 0) {
-        /* C^down_1 = gamma_1 / w_1 (drv:266-270); there is no up function yet */
-        if (chain == 1) {
-          if (lane == 0) {
-            Coef c;
-            c.Linear = 1.0;
-            c.Log = (double)(-coverage);
-            c.Constant = 0.0;
-            store_piece(lds_list(id_own_new), 0, c, a.contig_min_log_mean[contig],
-                        a.contig_max_log_mean[contig], -1, -5.0);
-          }
-          n_new = 1;
-        }
+        ArenaCursor cur0 = cur; /* only this copy has its address taken */
+        n_new = uniform_i(first_point(a, cur0, fn0, chain, contig, coverage, id_own_new));
+        cur = cur0;
       } else if (!in_hbm) {
 #ifdef PSD_CALL_LDS_OPS /* throughput build: operations out of line (register budget) */
         n_new = chain_step<USE_HELPER>(a, cur, fn0 + (unsigned long long)t, chain, t,
@@ -570,19 +582,19 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
               penalty / cum_weight_prev_i, cum_weight_prev_i, w, coverage, cum_weight_new);
         } else {
           ArenaCursor cur_gen = cur; /* only this copy has its address taken */
-          n_new = chain_step_lds<USE_HELPER>(
+          n_new = uniform_i(chain_step_lds<USE_HELPER>(
               a, cur_gen, fn0 + (unsigned long long)t, chain, t, id_other_prev, n_other,
               id_own_prev, n_own, id_own_new, penalty / cum_weight_prev_i, cum_weight_prev_i, w,
-              coverage, cum_weight_new);
+              coverage, cum_weight_new));
           cur = cur_gen;
         }
 #endif
       } else {
         ArenaCursor cur_hbm = cur; /* only this copy has its address taken */
-        n_new = chain_step_hbm(a, cur_hbm, fn0 + (unsigned long long)t, p, chain, t,
+        n_new = uniform_i(chain_step_hbm(a, cur_hbm, fn0 + (unsigned long long)t, p, chain, t,
                                id_other_prev, n_other, id_own_prev, n_own, id_own_new,
                                penalty / cum_weight_prev_i, cum_weight_prev_i, w, coverage,
-                               cum_weight_new);
+                               cum_weight_new));
         cur = cur_hbm;
       }
       /* ---- end of pass: report, store the backtrack record, meet the other wave ---- */
@@ -596,9 +608,6 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
                                     : ((-n_new) & WERR_OVERFLOW) ? PST_LDS_OVERFLOW
                                                                  : PST_REF_THROW;
         }
-      } else if (t == 0 && chain == 1) { /* down_0 is stored unscaled (drv:266-270,391) */
-        if (!arena_store_wave(a, cur, lds_list(id_own_new), n_new, fn0) && lane == 0)
-          g_sm.abort_status[slot] = PST_ARENA_FULL;
       }
       PSD_PROF_ADD(PROF_ARENA);
       block_sync(chain);
