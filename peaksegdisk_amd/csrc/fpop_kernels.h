@@ -256,10 +256,11 @@ PSD_D int chain_step(const DeviceArgs &a, ArenaCursor &cur, unsigned long long f
     }
   } else {
     const L f1 = chain == 0 ? mlist : mlist.shifted(cap - nm);
-    if (L::in_lds && nm <= 32 && n_own <= 32) {
+    n_new = -WERR_SERIAL;
+    if (L::in_lds && nm <= 32 && n_own <= 32)
       n_new = uniform_i(
           min_env_small_wave<HELP>(f1, nm, own_prev, n_own, own_new, cap, sc, chain));
-    } else {
+    if (n_new == -WERR_SERIAL) {
       n_new = uniform_i(min_env_wave<HELP>(f1, nm, own_prev, n_own, own_new, cap, sc, chain));
     }
   }
@@ -575,12 +576,14 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
                            penalty / cum_weight_prev_i, cum_weight_prev_i, w, coverage,
                            cum_weight_new);
 #else
+        n_new = -WERR_SERIAL;
         if (t >= 2 && n_other <= FAST_MAX_OTHER && n_own <= FAST_MAX_OWN) {
           n_new = chain_step_fast<USE_HELPER>(
               a, cur, fn0 + (unsigned long long)t, chain, t, lds_list(id_other_prev), n_other,
               lds_list(id_own_prev), n_own, lds_list(id_own_new), mlist, lsc,
               penalty / cum_weight_prev_i, cum_weight_prev_i, w, coverage, cum_weight_new);
-        } else {
+        }
+        if (n_new == -WERR_SERIAL) { /* not the usual case, or it needs the sequential replay */
           ArenaCursor cur_gen = cur; /* only this copy has its address taken */
           n_new = uniform_i(chain_step_lds<USE_HELPER>(
               a, cur_gen, fn0 + (unsigned long long)t, chain, t, id_other_prev, n_other,

@@ -341,6 +341,7 @@ enum {
   WERR_ZERO_INTERVAL = 8, /* fpl:933 zero-size merged interval */
   WERR_ARENA = 16,        /* the in-HBM store is full */
   WERR_HELPER = 32,       /* a helper wave did not answer (never expected) */
+  WERR_SERIAL = 64,       /* specialised min_env only: the step needs the sequential replay */
 };
 
 /* A lane's own copy of piece `lane` and of what the first pass computed for it (functions of
@@ -1857,6 +1858,8 @@ PSD_D int min_env_impl(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, i
     if (SMALL) break; /* K <= 64: one chunk */
   }
   if (need_serial) {
+    /* the specialised version leaves the replay (and the call it takes) to the general one */
+    if (SMALL) return -WERR_SERIAL;
     if (lane == 0) g_sm.serial[wave_id()]++;
     n_out = min_env_serial(f1, n1, f2, n2, out, cap, s, K);
     PSD_PROF_ADD(PROF_SERIAL);
