@@ -35,7 +35,7 @@
 #define PSD_VARIANT thr
 #define PSD_LDS_CAP 64
 #define PSD_KERNEL_WAVES_PER_EU 2
-#ifndef PSD_CALL_LDS_OPS
+#if !defined(PSD_CALL_LDS_OPS) && !defined(PSD_THR_INLINE_OPS) /* A/B: -DPSD_THR_INLINE_OPS */
 #define PSD_CALL_LDS_OPS 1
 #define PSD_CALL_LDS_OPS_THR_ONLY 1
 #endif
