@@ -192,7 +192,7 @@ def main():
             "kernel_build": pset.kernel_build,
             "serial_env_replays": int(sum(r.n_serial_env for r in results)),
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # the CPU baseline is timed at N=1 only
             out["cpu_baseline"] = cpu_baseline(cs, ce, cnt, pen_str, args.cpu_bins)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
