@@ -1857,6 +1857,9 @@ PSD_D int min_env_impl(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, i
     PSD_PROF_ADD(PROF_COMPACT);
     if (SMALL) break; /* K <= 64: one chunk */
   }
+#ifdef PSD_FORCE_SERIAL_ENV /* tests only: every envelope takes the sequential replay */
+  need_serial = true;
+#endif
   if (need_serial) {
     /* the specialised version leaves the replay (and the call it takes) to the general one */
     if (SMALL) return -WERR_SERIAL;

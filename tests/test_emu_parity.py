@@ -102,6 +102,44 @@ def test_emu_throughput_build(psd, oracle_det, tmp_path, monkeypatch):
     gp.test_throughput_build_identical(psd, oracle_det, tmp_path, monkeypatch, 400, 4)
 
 
+def test_emu_sequential_envelope_replay(oracle_det, tmp_path):
+    """min_env's compaction is only used when every "same function" decision is also a bitwise
+    equality; otherwise lane 0 replays the intervals sequentially (min_env_serial), and the
+    latency build's specialised step hands such a data point to the general step.  No data set
+    has needed that so far, so build the kernels with the replay forced for every envelope
+    and compare the whole store with the oracle's."""
+    import numpy as np
+    import peaksegdisk_amd  # noqa: F401
+    from peaksegdisk_amd import _native, synthetic
+    from peaksegdisk_amd.grid import ProblemSet
+    subprocess.run(["make", "-s", "-C", EMU_DIR, "all"], check=True)
+    lib = _native.declare(ctypes.CDLL(os.path.join(EMU_DIR, "_build",
+                                                   "libpeaksegdisk_emu_serial.so")))
+    cs, ce, cnt = synthetic.poisson_coverage(1000, seed=31)
+    pens = ["0.7", "60", "5000"]
+    bg = str(tmp_path / "coverage.bedGraph")
+    synthetic.write_bedgraph(bg, cs, ce, cnt)
+    for build in ("lat", "thr"):
+        os.environ["PEAKSEG_HIP_VARIANT"] = build
+        try:
+            pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))],
+                              [(0, float(p)) for p in pens], lib=lib)
+            pset.solve()
+        finally:
+            del os.environ["PEAKSEG_HIP_VARIANT"]
+        assert pset.kernel_build == build
+        for i, pen in enumerate(pens):
+            r = pset.result(i)
+            assert r.status == 0 and r.n_serial_env > 0
+            want = str(tmp_path / ("o_%d.db" % i))
+            if not os.path.exists(want):
+                assert oracle_det.solve(bg, pen, want) == 0
+            got = str(tmp_path / ("g_%s_%d.db" % (build, i)))
+            pset.export_db(i, ce, got)
+            assert open(got, "rb").read() == open(want, "rb").read(), (build, pen)
+        pset.close()
+
+
 def test_emu_grid_properties_small(psd):
     """The property checks of the full-size GPU test on a small grid (structure of the test
     itself; the arithmetic is the same)."""

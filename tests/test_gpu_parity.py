@@ -294,6 +294,41 @@ def test_throughput_build_identical(psd, oracle_det, tmp_path, monkeypatch, n_bi
 
 
 @GPU
+def test_sequential_envelope_replay(psd, oracle_det, tmp_path):
+    """The sequential replay of min_env (min_env_serial) and the way the latency build's
+    specialised step hands a data point over to the general step: no data set has needed them
+    so far, so a build with the replay forced for every envelope (-DPSD_FORCE_SERIAL_ENV) is
+    compared with the oracle on the device."""
+    import subprocess
+    import __graft_entry__ as entry
+    from conftest import ROOT
+    from peaksegdisk_amd import ProblemSet, _native, synthetic
+    csrc = os.path.join(ROOT, "peaksegdisk_amd", "csrc")
+    lib_path = str(tmp_path / "libpeaksegdisk_hip_serial.so")
+    subprocess.run([entry.HIPCC, "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17",
+                    "-ffp-contract=off", "-fPIC", "-shared", "-DPSD_FORCE_SERIAL_ENV",
+                    "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+                    os.path.join(csrc, "peakseg_hip.cpp"), "-o", lib_path], check=True)
+    lib = _native.declare(ctypes.CDLL(lib_path))
+    cs, ce, cnt = synthetic.poisson_coverage(5000, seed=31)
+    pens = ["0.7", "60", "5000"]
+    bg = str(tmp_path / "coverage.bedGraph")
+    synthetic.write_bedgraph(bg, cs, ce, cnt)
+    pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, float(p)) for p in pens],
+                      lib=lib)
+    pset.solve()
+    for i, pen in enumerate(pens):
+        r = pset.result(i)
+        assert r.status == 0 and r.n_serial_env > 0
+        want = str(tmp_path / ("o_%d.db" % i))
+        assert oracle_det.solve(bg, pen, want) == 0
+        got = str(tmp_path / ("g_%d.db" % i))
+        pset.export_db(i, ce, got)
+        assert open(got, "rb").read() == open(want, "rb").read(), pen
+    pset.close()
+
+
+@GPU
 def test_full_size_grid_properties(psd, oracle_det, tmp_path):
     """BASELINE.json configs[1] at full size (1e6 bins x 64 penalties): properties that do not
     need the oracle at that size, plus two penalties checked against the oracle outright.
