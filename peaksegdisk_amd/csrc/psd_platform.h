@@ -25,13 +25,9 @@
 #include <hip/hip_runtime.h>
 #define PSD_D __device__ __forceinline__
 #define PSD_M __device__ __forceinline__
-/* out-of-line device functions: keeps the forward kernel's hot loop inside the 64 KB
- * instruction cache (fully inlined it was ~200 KB) */
-#ifdef PSD_INLINE_WAVE_OPS /* experiment: everything inlined into the kernel */
-#define PSD_NOINLINE __device__ __forceinline__
-#else
+/* out-of-line device functions: what keeps the forward kernel's hot loop inside the 64 KB
+ * instruction cache (with everything inlined it was ~200 KB) */
 #define PSD_NOINLINE __device__ __attribute__((noinline))
-#endif
 #define PSD_LDS __shared__
 #define PSD_COLD_DEV __device__ __attribute__((noinline, cold))
 #endif
