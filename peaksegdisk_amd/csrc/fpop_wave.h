@@ -64,11 +64,13 @@ struct ScratchStore {
   int cls[LDS_CAP];
   int iv[2 * LDS_CAP];
 };
-/* Helper waves (PSD_HELPER_WAVES): every chain's main wave has a second wave that evaluates
- * independent parts of the envelope classification concurrently -- the mean-space midpoint
- * cost while the main wave computes the optimum of the difference piece, and the larger-root
- * Newton solves while the main wave does the smaller-root ones.  Lane k of the helper works
- * on lane k's interval; arguments and results cross through this LDS mailbox. */
+/* Helper waves (PSD_HELPER_WAVES): every chain's main wave has a second wave that runs the
+ * longest dependent chain of the envelope classification concurrently: given the difference
+ * piece of every interval (HOP_ROOT, posted as soon as it is formed), it derives the optimum
+ * and has_two_roots itself and does the larger-root Newton solves, while the main wave
+ * evaluates end costs, midpoint and the smaller-root solves.  Lane k of the helper works on
+ * lane k's interval; arguments and results cross through this LDS mailbox.  HOP_BARRIER makes
+ * the helper join a workgroup barrier, HOP_EXIT ends it. */
 enum { HOP_BARRIER = 1, HOP_EXIT = 2, HOP_ROOT = 3 };
 struct Mail {
   int seq_cmd, seq_done, op, abort;
