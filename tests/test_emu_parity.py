@@ -140,6 +140,10 @@ def test_emu_sequential_envelope_replay(oracle_det, tmp_path):
         pset.close()
 
 
+def test_emu_varied_data_shapes(psd, oracle_det, tmp_path, monkeypatch):
+    gp.test_varied_data_shapes(psd, oracle_det, tmp_path, monkeypatch, 6, 7)
+
+
 def test_emu_grid_properties_small(psd):
     """The property checks of the full-size GPU test on a small grid (structure of the test
     itself; the arithmetic is the same)."""

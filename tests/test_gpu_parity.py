@@ -293,6 +293,60 @@ def test_throughput_build_identical(psd, oracle_det, tmp_path, monkeypatch, n_bi
     other.close()
 
 
+def _shaped_counts(kind, n, rng):
+    if kind == 0:    # heavy-tailed counts
+        cnt = np.floor(rng.pareto(1.2, n) * 3)
+    elif kind == 1:  # long zero runs with bursts
+        cnt = np.where(rng.random(n) < 0.9, 0, rng.integers(1, 2000, n))
+    elif kind == 2:  # huge counts
+        cnt = rng.integers(0, 2000000, n)
+    elif kind == 3:  # slowly varying
+        cnt = (50 + 40 * np.sin(np.arange(n) / 37.0) + rng.normal(0, 3, n)).clip(0)
+    elif kind == 4:  # steps
+        cnt = np.repeat(rng.integers(0, 100, n // 50 + 1), 50)[:n]
+    else:            # 0/1 data
+        cnt = rng.random(n) < 0.3
+    return np.asarray(cnt).astype(np.int32)
+
+
+@GPU
+@pytest.mark.parametrize("n_cases,seed", [(18, 2024)])
+def test_varied_data_shapes(psd, oracle_det, tmp_path, monkeypatch, n_cases, seed):
+    """Coverage that does not look like the Poisson generator: heavy tails, long zero runs,
+    counts in the millions, smooth ramps, steps, 0/1 data, random bin widths and penalties
+    (0 included).  Both kernel builds; every stored function against the oracle's db."""
+    from peaksegdisk_amd import ProblemSet, synthetic
+    rng = np.random.default_rng(seed)
+    for case in range(n_cases):
+        n = int(rng.integers(500, 4000))
+        cnt = _shaped_counts(case % 6, n, rng)
+        w = rng.integers(1, 500, n).astype(np.int64)
+        ce = np.cumsum(w)
+        cs = ce - w
+        pens = ["0", "%.15g" % float(10 ** rng.uniform(-2, 6)),
+                "%.15g" % float(10 ** rng.uniform(0, 4))]
+        bg = str(tmp_path / ("c%d.bedGraph" % case))
+        synthetic.write_bedgraph(bg, cs, ce, cnt)
+        want = []
+        for i, pen in enumerate(pens):
+            db_o = str(tmp_path / ("o_%d_%d.db" % (case, i)))
+            assert oracle_det.solve(bg, pen, db_o) == 0
+            want.append(open(db_o, "rb").read())
+            os.unlink(db_o)
+        for build in ("lat", "thr"):
+            monkeypatch.setenv("PEAKSEG_HIP_VARIANT", build)
+            pset = ProblemSet([(cnt, w.astype(np.int32))], [(0, float(p)) for p in pens])
+            pset.solve()
+            assert pset.kernel_build == build
+            for i, pen in enumerate(pens):
+                assert pset.result(i).status == 0, (case, pen, build)
+                db_g = str(tmp_path / "g.db")
+                pset.export_db(i, ce.astype(np.int32), db_g)
+                assert open(db_g, "rb").read() == want[i], (case, pen, build)
+            pset.close()
+        monkeypatch.delenv("PEAKSEG_HIP_VARIANT")
+
+
 @GPU
 def test_sequential_envelope_replay(psd, oracle_det, tmp_path):
     """The sequential replay of min_env (min_env_serial) and the way the latency build's
