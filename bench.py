@@ -1,30 +1,42 @@
 #!/usr/bin/env python3
 """bench.py -- coverage bins/sec of the PeakSegFPOP hot path on a 64-penalty grid.
 
-A "step" is one pass of the hot path (forward functional-pruning DP + backtrack) over one
-batch: a seeded synthetic Poisson-coverage contig of --bins data points x --penalties
-log-spaced penalties, already resident in HBM when the timed region starts.  At N GPUs every
-rank solves its own contig x penalty grid (independent problems, weak scaling) and the
-segment tables are gathered to rank 0 over RCCL inside the timed region.
+A "step" is one pass of the hot path (forward functional-pruning DP + decoding) over one
+batch of synthetic input that is already resident in HBM when the timed region starts.
+
+  --mode weak (default)  BASELINE.json configs[1] per GPU: a seeded synthetic Poisson-coverage
+                         contig of --bins data points x --penalties log-spaced penalties.  At N
+                         GPUs every rank solves its own contig x penalty grid (independent
+                         problems, weak scaling); the segment tables are gathered to rank 0
+                         over RCCL inside the timed region.
+  --mode grid            BASELINE.json configs[3]: 24 contigs, lengths log-uniform in
+                         [1e5, 1e7] x --grid-scale, x --penalties penalties, dealt longest-first
+                         to the ranks (peaksegdisk_amd.parallel.solve_grid; strong scaling:
+                         the work is fixed, upload and gather are inside the timed region).
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
+itself (python -m torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1)
+before anything touches the GPU, and exits with their return code; under torchrun it is a
+rank.  Every rank checks that the world size equals --gpus.
 
 Prints ONE JSON line (rank 0): metric/value/unit per BASELINE.json, plus
   roofline     -- the kernel (forward pass with the decoding fused in): algorithmic HBM bytes
                   (24 B per (bin,penalty) + 20 B per stored piece; decoding: per
                   segment 12 B written, 8 B + 28 B per piece of the function read) / HIP-event
-                  kernel time, against 8 TB/s
+                  kernel time (events on the stream the kernel runs on), against 8 TB/s
   cpu_baseline -- the CPU oracle (libm build, disk-backed store like the reference) timed on
-                  a bounded sample of the same workload on this host.
+                  a bounded sample of the same workload on this host: one core, and all cores
+                  with a process pool (N=1 only).
 """
 import argparse
 import json
 import os
 import shutil
+import socket
 import subprocess
 import sys
 import tempfile
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -32,55 +44,145 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(chrom_start, chrom_end, count, penalties, budget_bins):
-    """Time oracle_cli_libm (one process per (contig, penalty), db on local scratch) on a
-    bounded sample: the first `budget_bins` data points at a spread of the grid's penalties."""
-    cli = os.path.join(ROOT, "oracle", "_build", "oracle_cli_libm")
-    if not os.path.exists(cli):
-        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
-    from peaksegdisk_amd import synthetic
-    n = min(budget_bins, len(count))
-    pick = sorted(set(np.linspace(0, len(penalties) - 1, 8).round().astype(int).tolist()))
-    work = tempfile.mkdtemp(prefix="psd_cpu_")
-    try:
-        bg = os.path.join(work, "coverage.bedGraph")
-        synthetic.write_bedgraph(bg, chrom_start[:n], chrom_end[:n], count[:n])
-        t0 = time.time()
-        for i in pick:
-            st = subprocess.run([cli, bg, penalties[i], os.path.join(work, "db")]).returncode
-            if st != 0:
-                raise RuntimeError("oracle_cli_libm status %d" % st)
-        wall = time.time() - t0
-    finally:
-        shutil.rmtree(work, ignore_errors=True)
-    return {
-        "value": n * len(pick) / wall, "unit": "bins/s", "cores": 1, "kind": "port",
-        "sample": "first %d bins of the contig x %d of the %d penalties, oracle_cli_libm "
-                  "(C restatement, glibc exp/log, disk-backed store), one process per problem, "
-                  "%.1f s" % (n, len(pick), len(penalties), wall),
-    }
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", choices=["weak", "grid"], default="weak")
     ap.add_argument("--bins", type=int, default=1000000)
     ap.add_argument("--penalties", type=int, default=64)
-    ap.add_argument("--cpu-bins", type=int, default=200000)
+    ap.add_argument("--grid-contigs", type=int, default=24)
+    ap.add_argument("--grid-scale", type=float, default=1.0,
+                    help="grid mode: contig lengths are log-uniform in [1e5, 1e7] x this")
+    ap.add_argument("--cpu-bins", type=int, default=40000,
+                    help="CPU baseline, one core: first this many bins x every penalty")
+    ap.add_argument("--cpu-bins-all", type=int, default=200000,
+                    help="CPU baseline, all cores: first this many bins x every penalty")
     ap.add_argument("--no-cpu", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(chrom_start, chrom_end, count, penalties, bins_one, bins_all):
+    """Time oracle_cli_libm -- one process per (contig, penalty), cost-function database on
+    local scratch, as the reference runs -- on a bounded sample of the bench workload: the
+    first bins of the contig at EVERY penalty of the grid, (i) one process at a time on one
+    core and (ii) a pool with one worker per host core.  kind = "port": the reference's own
+    solver sources include R.h, which this image lacks, so they cannot be built here
+    (DESIGN.md section 2); the oracle is the C restatement pinned by the reference's fixtures."""
+    from concurrent.futures import ThreadPoolExecutor
+    from peaksegdisk_amd import synthetic
+    cli = os.path.join(ROOT, "oracle", "_build", "oracle_cli_libm")
+    if not os.path.exists(cli):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    work = tempfile.mkdtemp(prefix="psd_cpu_")
+
+    def run_one(bg, pen, k):
+        st = subprocess.run([cli, bg, pen, os.path.join(work, "db%d" % k)],
+                            stdout=subprocess.DEVNULL).returncode
+        if st != 0:
+            raise RuntimeError("oracle_cli_libm status %d" % st)
+
+    try:
+        n1 = min(bins_one, len(count))
+        bg1 = os.path.join(work, "one", "coverage.bedGraph")
+        os.makedirs(os.path.dirname(bg1))
+        synthetic.write_bedgraph(bg1, chrom_start[:n1], chrom_end[:n1], count[:n1])
+        t0 = time.time()
+        for k, pen in enumerate(penalties):
+            run_one(bg1, pen, k)
+        wall1 = time.time() - t0
+        n2 = min(bins_all, len(count))
+        bg2 = os.path.join(work, "all", "coverage.bedGraph")
+        os.makedirs(os.path.dirname(bg2))
+        synthetic.write_bedgraph(bg2, chrom_start[:n2], chrom_end[:n2], count[:n2])
+        t0 = time.time()
+        with ThreadPoolExecutor(max_workers=cores) as pool:  # each task is one child process
+            list(pool.map(lambda kp: run_one(bg2, kp[1], 1000 + kp[0]), enumerate(penalties)))
+        wall2 = time.time() - t0
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return {
+        "value": n1 * len(penalties) / wall1, "unit": "bins/s", "cores": 1, "kind": "port",
+        "sample": "first %d bins of the contig x all %d penalties, oracle_cli_libm (C "
+                  "restatement, glibc exp/log, disk-backed store), one process per problem, "
+                  "one at a time, %.1f s" % (n1, len(penalties), wall1),
+        "all_cores": {
+            "value": n2 * len(penalties) / wall2, "unit": "bins/s", "cores": cores,
+            "sample": "first %d bins x all %d penalties, pool of %d processes, %.1f s"
+                      % (n2, len(penalties), cores, wall2),
+        },
+        "cpu_model": cpu_model_name(),
+        "why_port": "the reference's solver sources include R.h (absent here): unbuildable, "
+                    "see DESIGN.md section 2",
+    }
+
+
+def grid_contig_lengths(n_contigs, scale):
+    """configs[3]: contig lengths log-uniform in [1e5, 1e7] (x scale), seeded."""
+    from peaksegdisk_amd import synthetic
+    u = synthetic.uniform01(20241001, 9, n_contigs)
+    return [max(64, int(round(scale * 10.0 ** (5.0 + 2.0 * x)))) for x in u]
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """--gpus N without a torchrun environment: build once, then start N ranks as children
+    (never by replacing this process) and return their exit code."""
+    import __graft_entry__ as entry
+    if not os.environ.get("PSD_BENCH_TEST_LIB"):
+        entry.build_hip()
+    entry.build_oracle()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
-    dist = None
-    # RCCL ("nccl") on GPUs; tests/test_bench_multirank.py rehearses the N>1 plumbing on CPU
-    # with PSD_BENCH_BACKEND=gloo
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # RCCL ("nccl") on GPUs; tests rehearse the N>1 plumbing on CPU with PSD_BENCH_BACKEND=gloo
+    # and the kernels under the SIMT emulator (PSD_BENCH_TEST_LIB, honoured only with gloo)
     backend = os.environ.get("PSD_BENCH_BACKEND", "nccl")
     on_gpu = backend == "nccl"
+    import numpy as np
+    import __graft_entry__ as entry
+    if world == 1 and not os.environ.get("PSD_BENCH_TEST_LIB"):
+        entry.build_hip()  # N > 1: the launcher (or the driver's build step) has built it
+    import torch
+    dist = None
     if world > 1:
         import torch.distributed as dist
         if on_gpu:
@@ -88,22 +190,17 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus
     device = local_rank if (world > 1 and on_gpu) else 0
-
-    import __graft_entry__ as entry
-    if rank == 0 or not os.path.exists(entry.LIB):
-        entry.build_hip()
-    if dist is not None:
-        dist.barrier()
+    from peaksegdisk_amd import _native
+    if not on_gpu and os.environ.get("PSD_BENCH_TEST_LIB"):
+        import ctypes
+        _native.lib = _native.declare(ctypes.CDLL(os.environ["PSD_BENCH_TEST_LIB"]))
     from peaksegdisk_amd import ProblemSet, synthetic
-    from peaksegdisk_amd.parallel import gather_segment_tables
+    from peaksegdisk_amd.parallel import gather_segment_tables, solve_grid
 
-    # every rank: its own contig (seed 1 + rank), the same penalty grid
-    cs, ce, cnt = synthetic.poisson_coverage(args.bins, seed=1 + rank)
-    weight = (ce - cs).astype(np.int32)
     pen_str = synthetic.penalty_grid(args.penalties)
-    problems = [(0, float(p)) for p in pen_str]
-    pset = ProblemSet([(cnt, weight)], problems, device=device)
+    penalties = [float(p) for p in pen_str]
 
     def sync():
         if on_gpu:
@@ -111,11 +208,37 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def one_step():
-        f_ms, _ = pset.solve()
-        tables = [pset.segments(p) for p in range(len(problems))]
-        gathered = gather_segment_tables(tables, dist, device)
-        return f_ms, gathered
+    extra = {}
+    if args.mode == "weak":
+        # every rank: its own contig (seed 1 + rank), the same penalty grid
+        cs, ce, cnt = synthetic.poisson_coverage(args.bins, seed=1 + rank)
+        weight = (ce - cs).astype(np.int32)
+        problems = [(0, p) for p in penalties]
+        t_c = time.time()
+        pset = ProblemSet([(cnt, weight)], problems, device=device)
+        create_s = time.time() - t_c
+
+        def one_step():
+            f_ms, _ = pset.solve()
+            tables = [pset.segments(p) for p in range(len(problems))]
+            gathered = gather_segment_tables(tables, dist, device)
+            return f_ms, gathered
+
+        units_per_step = args.bins * args.penalties * world
+    else:
+        lengths = grid_contig_lengths(args.grid_contigs, args.grid_scale)
+        contigs = []
+        for c, n in enumerate(lengths):
+            s_, e_, k_ = synthetic.poisson_coverage(n, seed=101 + c)
+            contigs.append((k_, (e_ - s_).astype(np.int32)))
+        stats = {}
+
+        def one_step():
+            out = solve_grid(contigs, penalties, dist, device, stats=stats)
+            return stats.get("forward_ms", 0.0), out
+
+        units_per_step = sum(lengths) * args.penalties
+        create_s = None
 
     for _ in range(args.warmup):
         one_step()
@@ -133,31 +256,72 @@ def main():
         elapsed = float(t.item())
 
     # parity gate on what was just computed: structural checks that hold for every solution
-    results = [pset.result(p) for p in range(len(problems))]
-    for p, r in enumerate(results):
-        assert r.status == 0, "problem %d failed with kernel status %d" % (p, r.kernel_status)
-        start, mean = pset.segments(p)
-        assert len(start) == r.n_segments and len(start) % 2 == 1
-        assert start[-1] == -1 and (np.diff(start[:-1]) < 0).all()
-
-    if rank == 0:
-        # HBM traffic of one forward launch from the PMC counters (collected separately with
-        # rocprofv3 --pmc, see profiles/r01/pmc_traffic.json); only valid for that workload
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            if pmc["workload"]["bins"] == args.bins and \
-                    pmc["workload"]["penalties"] == args.penalties:
-                traffic = pmc["traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
-        units = args.bins * args.penalties * world * args.steps
+    if args.mode == "weak":
+        results = [pset.result(p) for p in range(len(problems))]
+        for p, r in enumerate(results):
+            assert r.status == 0, "problem %d failed with kernel status %d" % (p, r.kernel_status)
+            start, mean = pset.segments(p)
+            assert len(start) == r.n_segments and len(start) % 2 == 1
+            assert start[-1] == -1 and (np.diff(start[:-1]) < 0).all()
         total_pieces = sum(r.total_intervals for r in results)
-        alg_bytes = 24.0 * args.bins * args.penalties + 20.0 * total_pieces
+        bins_launch = args.bins * args.penalties
+        alg_bytes = 24.0 * bins_launch + 20.0 * total_pieces
         for r in results:  # decoding: one function looked up per segment
             alg_bytes += r.n_segments * (20.0 + 28.0 * r.total_intervals / (2.0 * args.bins))
+        extra = {"hbm_bytes_resident": pset.hbm_bytes, "arena_bytes_used": pset.arena_bytes_used,
+                 "kernel_build": pset.kernel_build,
+                 "serial_env_replays": int(sum(r.n_serial_env for r in results))}
+    elif rank == 0:
+        assert len(gathered) == len(lengths) * len(penalties)
+        total_pieces = 0.0
+        alg_bytes = 0.0
+        for (c, p), res in gathered.items():
+            n_seg, _, _, tot, _ = res["summary"]
+            assert len(res["seg_start"]) == int(n_seg) and res["seg_start"][-1] == -1
+            total_pieces += tot
+            alg_bytes += n_seg * (20.0 + 28.0 * tot / (2.0 * lengths[c]))
+        bins_launch = sum(lengths) * args.penalties
+        alg_bytes += 24.0 * bins_launch + 20.0 * total_pieces
+        # the ranks' kernels run concurrently: rank 0's launch moves about its share
+        alg_bytes /= world
+        bins_launch /= world
+        extra = {"kernel_build": stats.get("kernel_build"),
+                 "hbm_bytes_resident": stats.get("hbm_bytes")}
+
+    if rank == 0:
+        units = units_per_step * args.steps
+        # HBM traffic of one forward launch from the PMC counters (collected separately with
+        # rocprofv3 --pmc by tools/collect_profiles.sh); only valid for that workload
+        traffic = None
+        if args.mode == "weak":
+            for rnd in ("r02", "r01"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as f:
+                        pmc = json.load(f)
+                    if pmc["workload"]["bins"] == args.bins and \
+                            pmc["workload"]["penalties"] == args.penalties:
+                        traffic = pmc["traffic_bytes_per_launch"]
+                        extra["traffic_source"] = "profiles/%s/pmc_traffic.json" % rnd
+                        break
+                except (OSError, KeyError, ValueError):
+                    pass
         fwd_s = float(np.mean(fwd)) / 1e3
+        if args.mode == "weak":
+            workload = ("%d-bin synthetic Poisson coverage x %d-penalty grid per GPU "
+                        "(BASELINE.json configs[1])" % (args.bins, args.penalties))
+            cfg = {"workload": workload, "bins": args.bins, "penalties": args.penalties,
+                   "penalty_grid": "10^seq(-1,5), 15 significant digits", "seed": "1+rank",
+                   "sharding": "independent (contig x penalty) problems per rank; RCCL gather "
+                               "of segment tables to rank 0"}
+        else:
+            workload = ("%d synthetic contigs of %d..%d bins (log-uniform) x %d penalties "
+                        "dealt longest-first to %d rank(s) (BASELINE.json configs[3])"
+                        % (len(lengths), min(lengths), max(lengths), args.penalties, world))
+            cfg = {"workload": workload, "contigs": len(lengths), "total_bins": sum(lengths),
+                   "penalties": args.penalties, "grid_scale": args.grid_scale,
+                   "sharding": "LPT dealing of (contig x penalty) problems; one RCCL gather of "
+                               "segment tables + summaries to rank 0; upload inside the timed "
+                               "region"}
         out = {
             "metric": "coverage bins/sec across 64-penalty grid",
             "value": units / elapsed,
@@ -167,36 +331,38 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if args.mode == "weak" else "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {
-                "workload": "%d-bin synthetic Poisson coverage x %d-penalty grid per GPU "
-                            "(BASELINE.json configs[1])" % (args.bins, args.penalties),
-                "bins": args.bins, "penalties": args.penalties,
-                "penalty_grid": "10^seq(-1,5), 15 significant digits", "seed": "1+rank",
-                "sharding": "independent (contig x penalty) problems per rank; RCCL gather of "
-                            "segment tables to rank 0",
-            },
+            "config": cfg,
             "roofline": {
                 "bound": "hbm", "kernel": "fpop_forward_kernel",
-                "achieved": alg_bytes / fwd_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": alg_bytes / fwd_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                "achieved": alg_bytes / fwd_s / 1e9 if fwd_s > 0 else None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg_bytes / fwd_s / 1e9 / HBM_PEAK_GBS if fwd_s > 0 else None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": float(np.mean(fwd)),  # forward pass + decoding, one launch
-                "dp_steps_per_s_per_problem": args.bins / fwd_s,
-                "mean_intervals": total_pieces / (2.0 * args.bins * args.penalties),
+                "dp_steps_per_s_per_problem":
+                    (args.bins / fwd_s if args.mode == "weak" and fwd_s > 0 else None),
+                "mean_intervals": total_pieces / (2.0 * bins_launch * (world if args.mode == "grid" else 1)),
             },
-            "hbm_bytes_resident": pset.hbm_bytes,
-            "kernel_build": pset.kernel_build,
-            "serial_env_replays": int(sum(r.n_serial_env for r in results)),
         }
-        if not args.no_cpu and world == 1:  # the CPU baseline is timed at N=1 only
-            out["cpu_baseline"] = cpu_baseline(cs, ce, cnt, pen_str, args.cpu_bins)
+        out.update(extra)
+        if create_s is not None:
+            # the same step with upload + allocation counted (PCIe-inclusive, never `value`)
+            out["value_incl_upload"] = units_per_step / world / \
+                (create_s + elapsed / args.steps)
+            out["upload_alloc_s"] = create_s
+        if not args.no_cpu and world == 1 and args.mode == "weak":
+            out["cpu_baseline"] = cpu_baseline(cs, ce, cnt, pen_str, args.cpu_bins,
+                                               args.cpu_bins_all)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["gpu_over_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["all_cores"]["value"]
         print(json.dumps(out))
-    pset.close()
+    if args.mode == "weak":
+        pset.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -14,7 +14,8 @@
  * Returns t = tail_j + p(r) and hi_j; *kq = 128 k + j. */
 PSD_HD static inline double PSD_FN(psd_exp_core)(double x, long long *kq, double *hi) {
   const double shift = PSD_K(0x1.8p52);
-  double z = x * PSD_K(PSD_INV_LN2N) + shift; /* low mantissa bits = rint(x * 128/ln2) */
+  /* one rounding: the low mantissa bits of z are rint(x * 128/ln2) */
+  double z = psd_fma(x, PSD_K(PSD_INV_LN2N), shift);
   long long ki = (long long)psd_d2u(z) - (long long)0x4338000000000000LL;
   double kd = z - shift;
   double r = psd_fma(kd, PSD_K(-PSD_LN2N_HI), x);
@@ -41,9 +42,13 @@ PSD_HD static inline double PSD_FN(psd_exp)(double x) {
   /* scale = 2^k * hi_j: add k to the exponent field */
   double scale = psd_u2d(psd_d2u(hi) + ((uint64_t)(kq >> 7) << 52));
   double y = psd_fma(scale, t, scale);
+  /* The rare-argument test is ONE wave-uniform branch on the device (v_cmp + s_cbranch_vccz);
+   * behind it every lane evaluates the slow form and the rare ones keep it: no exec-mask
+   * bracket around the common path. */
   const int rare = !(__builtin_fabs(x) <= 708.0);
   if (PSD_ANY_LANE(rare)) {
-    if (rare) y = psd_exp_slow(x);
+    const double ys = psd_exp_slow(x);
+    y = rare ? ys : y;
   }
   return y;
 }
@@ -56,10 +61,12 @@ PSD_HD static inline double PSD_FN(psd_exp)(double x) {
  * low word.  For x near 1 (J = 0 with k = 0, or J = 128 with k = -1) the table terms cancel
  * exactly and the result keeps full relative accuracy. */
 PSD_HD static inline double PSD_FN(psd_log_core)(uint64_t hx, int k0) {
-  int k = k0 + (int)(hx >> 52) - 1023;
-  uint64_t mant = hx & 0x000fffffffffffffULL;
-  int J = (int)((mant + 0x0000100000000000ULL) >> 45);
-  double m = psd_u2d(mant | 0x3ff0000000000000ULL);
+  /* exponent, table index and mantissa all come from the high word (32-bit integer work) */
+  const uint32_t top = (uint32_t)(hx >> 32);
+  int k = k0 + (int)(top >> 20) - 1023;
+  const uint32_t mant_hi = top & 0x000fffffu;
+  int J = (int)((mant_hi + 0x00001000u) >> 13);
+  double m = psd_u2d(((uint64_t)(mant_hi | 0x3ff00000u) << 32) | (uint32_t)hx);
   double invc = PSD_T_INVC(J);
   double logc_hi = PSD_T_LOGC_HI(J);
   double logc_lo = PSD_T_LOGC_LO(J);
@@ -80,10 +87,11 @@ PSD_HD static inline double PSD_FN(psd_log_core)(uint64_t hx, int k0) {
 PSD_HD static inline double PSD_FN(psd_log)(double x) {
   uint64_t hx = psd_d2u(x);
   double y = PSD_FN(psd_log_core)(hx, 0);
-  /* anything but positive, normal, finite: one unsigned compare */
-  const int rare = !(hx - 0x0010000000000000ULL < 0x7fe0000000000000ULL);
+  /* anything but positive, normal, finite: one unsigned compare of the high word */
+  const int rare = !((uint32_t)(hx >> 32) - 0x00100000u < 0x7fe00000u);
   if (PSD_ANY_LANE(rare)) {
-    if (rare) y = psd_log_slow(x);
+    const double ys = psd_log_slow(x);
+    y = rare ? ys : y;
   }
   return y;
 }

@@ -29,7 +29,22 @@ extern "C" {
 /* additions of this implementation (the reference reports "error code %d" for them) */
 #define ERROR_NO_HIP_DEVICE 12     /* no MI355X visible: there is no CPU fallback */
 #define ERROR_DEVICE_SOLVER 13     /* kernel reported a failure; see peakseg_hip_last_error() */
-#define ERROR_DEVICE_MEMORY 14     /* arena / tables do not fit in HBM */
+#define ERROR_DEVICE_MEMORY 14     /* arena / tables do not fit in HBM (or in PEAKSEG_HIP_MAX_BYTES) */
+#define ERROR_SEARCH_ARGUMENTS 15  /* PeakSegFPOP_sequential_search: bad arguments / row capacity */
+#define ERROR_SEARCH_TOO_MANY_PEAKS 16 /* peaks.int exceeds the maximum for the data; the text of
+                                          R/sequentialSearch_dir.R:57-66 is in peakseg_hip_last_error() */
+
+/* ---- environment ---------------------------------------------------------------------
+ * PEAKSEG_HIP_DEVICE            GPU used by the file-level entry points (default 0); one process
+ *                               per GPU sets it from its rank
+ * PEAKSEG_HIP_MAX_BYTES         cap on the HBM one problem set may hold (suffix K/M/G/T); several
+ *                               processes can then share one GPU (R's future workers)
+ * PEAKSEG_HIP_PIECES_PER_FUNCTION  arena estimate, pieces per stored cost function (default 16;
+ *                               the arena is doubled and the set rerun when it proves too small)
+ * PEAKSEG_HIP_SPILL_CAP / _SPILL_SLOTS  capacity (pieces per list, at most 32767) and initial
+ *                               number of slots of the HBM spill pool for functions that outgrow LDS
+ * PEAKSEG_HIP_VARIANT=lat|thr   force a build of the forward kernel
+ * PEAKSEG_HIP_TIMING=1          phase timings of the file-level calls on stderr */
 
 /* ---- the reference's boundary -------------------------------------------------------- */
 
@@ -49,6 +64,38 @@ int PeakSegFPOP_disk(char *bedGraph_file_name, char *penalty_str, char *db_file_
  * receives each problem's status; the return value is the first non-zero one (0 if none). */
 int PeakSegFPOP_disk_batch(int n_problems, char **bedGraph_files, char **penalty_strs,
                            char **db_files, int *status_out);
+
+/* PeakSegFPOP_dir for a batch of (problem directory, penalty string) pairs
+ * (/root/reference/R/PeakSegFPOP_dir.R:64-117 over R/PeakSegFPOP_file.R:57-86): pairs whose
+ * coverage.bedGraph_penalty=<pen>_{segments.bed,loss.tsv,timing.tsv} files exist and pass the
+ * reference's consistency test are skipped (cached_out[i] = 1); the rest are solved in one
+ * PeakSegFPOP_disk_batch (default database name, removed afterwards) and get their _timing.tsv
+ * (penalty, megabytes = size of the reference's database / 2^20, seconds = the problem's share
+ * of the batch's wall time).  Returns the first non-zero status (0 if none). */
+int PeakSegFPOP_dir_batch(int n_problems, char **problem_dirs, char **penalty_strs,
+                          int *status_out, int *cached_out);
+
+/* One model visited by the penalty search: a row of sequentialSearch_dir's $others. */
+typedef struct {
+  char penalty_str[40];  /* paste(penalty): names the result files of this model */
+  double penalty;        /* loss.tsv column 1 */
+  double total_loss;     /* loss.tsv column 7 */
+  int peaks, segments, bases;
+  int iteration;         /* 1-based */
+  int under_peaks, over_peaks; /* peaks of the bracket when the model was requested; INT_MIN = NA */
+  int cached;            /* result files were reused, no dynamic program ran */
+} psd_search_row;
+
+/* sequentialSearch_dir(problem.dir, peaks.int) (/root/reference/R/sequentialSearch_dir.R:22-103)
+ * next to the solver: the same loop, the same penalties (R's 15-significant-digit paste() of
+ * each secant step) and the same files as the reference leaves behind for every model --
+ * PeakSegFPOP_dir's cache included -- but coverage.bedGraph is parsed and uploaded once and the
+ * arena is reused from one penalty to the next.  rows[0..*n_rows) are the models in the order
+ * they were requested (iteration 1: "0" then "Inf"); *chosen_row is the returned model.
+ * Status: 0, a solver status, ERROR_SEARCH_TOO_MANY_PEAKS or ERROR_SEARCH_ARGUMENTS. */
+int PeakSegFPOP_sequential_search(const char *problem_dir, int peaks_int, int verbose,
+                                  int row_capacity, psd_search_row *rows, int *n_rows,
+                                  int *chosen_row);
 
 /* The text the reference's glue passes to Rf_error for a status
  * (/root/reference/src/interface.cpp:16-55); returns buf; empty string for status 0. */
@@ -118,6 +165,13 @@ const char *peakseg_hip_problem_set_kernel_build(psd_problem_set *set);
 /* bytes of HBM held by the set (arena + tables) */
 unsigned long long peakseg_hip_problem_set_bytes(psd_problem_set *set);
 
+/* bytes of the arena the last solve handed out (whole chunks) */
+unsigned long long peakseg_hip_problem_set_arena_bytes_used(psd_problem_set *set);
+
+/* Change one problem's penalty in place (the contig stays resident, the arena is reused by the
+ * next solve): what the penalty search does between its dynamic programs.  0 or -1. */
+int peakseg_hip_problem_set_set_penalty(psd_problem_set *set, int problem, double penalty);
+
 void peakseg_hip_problem_set_destroy(psd_problem_set *set);
 
 /* Tests: parse a bedGraph file the way PeakSegFPOP_disk does (use_fast != 0: byte scanner with
@@ -125,6 +179,10 @@ void peakseg_hip_problem_set_destroy(psd_problem_set *set);
  * number of data lines and a hash of everything parsed. */
 int peakseg_hip_parse_probe(const char *path, int use_fast, int *n_lines,
                             unsigned long long *hash);
+
+/* Tests: R's paste() of a double (15 significant digits) as the penalty search and the timing
+ * files format numbers; returns the length. */
+int peakseg_hip_paste_double(double x, char *buf, size_t buf_len);
 
 /* diagnostic builds (-DPSD_PROFILE): per-wave cycle counters of the forward kernel; -1 in
  * normal builds */

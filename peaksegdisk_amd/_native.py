@@ -31,6 +31,26 @@ class PsdResult(ctypes.Structure):
     ]
 
 
+class PsdSearchRow(ctypes.Structure):
+    _fields_ = [
+        ("penalty_str", ctypes.c_char * 40),
+        ("penalty", ctypes.c_double),
+        ("total_loss", ctypes.c_double),
+        ("peaks", ctypes.c_int),
+        ("segments", ctypes.c_int),
+        ("bases", ctypes.c_int),
+        ("iteration", ctypes.c_int),
+        ("under_peaks", ctypes.c_int),
+        ("over_peaks", ctypes.c_int),
+        ("cached", ctypes.c_int),
+    ]
+
+
+ERROR_SEARCH_ARGUMENTS = 15
+ERROR_SEARCH_TOO_MANY_PEAKS = 16
+SEARCH_NA = -2 ** 31
+
+
 def declare(lib):
     """Attach argtypes/restypes for every symbol of include/peaksegdisk_hip.h."""
     c = ctypes
@@ -78,6 +98,20 @@ def declare(lib):
     lib.peakseg_hip_problem_set_profile.restype = c.c_int
     lib.peakseg_hip_math_probe.argtypes = [c.c_int, c.c_int, c.c_void_p, c.c_void_p]
     lib.peakseg_hip_math_probe.restype = c.c_int
+    lib.PeakSegFPOP_dir_batch.argtypes = [
+        c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_char_p), c.POINTER(c.c_int),
+        c.POINTER(c.c_int)]
+    lib.PeakSegFPOP_dir_batch.restype = c.c_int
+    lib.PeakSegFPOP_sequential_search.argtypes = [
+        c.c_char_p, c.c_int, c.c_int, c.c_int, c.POINTER(PsdSearchRow), c.POINTER(c.c_int),
+        c.POINTER(c.c_int)]
+    lib.PeakSegFPOP_sequential_search.restype = c.c_int
+    lib.peakseg_hip_problem_set_set_penalty.argtypes = [c.c_void_p, c.c_int, c.c_double]
+    lib.peakseg_hip_problem_set_set_penalty.restype = c.c_int
+    lib.peakseg_hip_problem_set_arena_bytes_used.argtypes = [c.c_void_p]
+    lib.peakseg_hip_problem_set_arena_bytes_used.restype = c.c_ulonglong
+    lib.peakseg_hip_paste_double.argtypes = [c.c_double, c.c_char_p, c.c_size_t]
+    lib.peakseg_hip_paste_double.restype = c.c_int
     return lib
 
 
@@ -89,6 +123,9 @@ EXPORTED_SYMBOLS = [
     "peakseg_hip_problem_set_export_db", "peakseg_hip_problem_set_bytes",
     "peakseg_hip_problem_set_destroy", "peakseg_hip_math_probe", "peakseg_hip_parse_probe",
     "peakseg_hip_problem_set_profile", "peakseg_hip_problem_set_kernel_build",
+    "PeakSegFPOP_dir_batch", "PeakSegFPOP_sequential_search",
+    "peakseg_hip_problem_set_set_penalty", "peakseg_hip_problem_set_arena_bytes_used",
+    "peakseg_hip_paste_double",
 ]
 
 if not os.path.exists(LIB_PATH):

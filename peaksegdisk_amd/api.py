@@ -304,66 +304,78 @@ def PeakSegFPOP_vec(count_vec, pen_num):
     return PeakSegFPOP_df(coverage_df, pen_num)
 
 
+# ---- PeakSegFPOP_dir for a batch (additive) --------------------------
+
+def PeakSegFPOP_dir_batch(problem_dirs, penalty_params):
+    """PeakSegFPOP_dir for many (problem.dir, penalty) pairs in one call of the native
+    PeakSegFPOP_dir_batch: cached results are reused as PeakSegFPOP_dir would
+    (R/PeakSegFPOP_dir.R:70-93), every other pair is solved in one device problem set (one
+    parse and upload per distinct coverage.bedGraph) and gets its _timing.tsv.  Returns the
+    list of PeakSegFPOP_dir results, in order; `.cached` says which were reused."""
+    import ctypes
+    if len(problem_dirs) != len(penalty_params):
+        raise ValueError("problem_dirs and penalty_params must have the same length")
+    n = len(problem_dirs)
+    pens = [paste(p) for p in penalty_params]
+    dirs = (ctypes.c_char_p * n)(*[os.fsencode(d) for d in problem_dirs])
+    pstr = (ctypes.c_char_p * n)(*[p.encode() for p in pens])
+    status = (ctypes.c_int * n)()
+    cached = (ctypes.c_int * n)()
+    _native.lib.PeakSegFPOP_dir_batch(n, dirs, pstr, status, cached)
+    out = []
+    for i in range(n):
+        bg = os.path.join(problem_dirs[i], "coverage.bedGraph")
+        if status[i] != 0:
+            msg = _native.status_message(status[i], os.path.realpath(bg), pens[i],
+                                         "%s_penalty=%s.db" % (os.path.realpath(bg), pens[i]))
+            raise PeakSegError(status[i], msg)
+        L = PeakSegFPOP_dir(problem_dirs[i], pens[i])  # reads the files just written (cache hit)
+        L.cached = bool(cached[i])
+        out.append(L)
+    return out
+
+
 # ---- sequentialSearch_dir (R/sequentialSearch_dir.R:22-103) --------------------------------
 
 def sequentialSearch_dir(problem_dir, peaks_int, verbose=0):
+    """The reference's penalty search for a target number of peaks.  The loop itself runs in
+    the native library (PeakSegFPOP_sequential_search: coverage.bedGraph parsed and uploaded
+    once, arena reused from one penalty to the next); it visits the reference's penalties and
+    leaves the reference's files, from which the result is assembled here."""
+    import ctypes
     if not (isinstance(peaks_int, (int, np.integer)) and not isinstance(peaks_int, bool)
             and 0 <= peaks_int):
         raise ValueError("is.integer(peaks.int) && length(peaks.int) == 1 && 0 <= peaks.int "
                          "is not TRUE")
     if not isinstance(problem_dir, str):
         raise ValueError("is.character(problem.dir) is not TRUE")
+    cap = 256
+    rows = (_native.PsdSearchRow * cap)()
+    n_rows = ctypes.c_int(0)
+    chosen = ctypes.c_int(-1)
+    st = _native.lib.PeakSegFPOP_sequential_search(
+        os.fsencode(problem_dir), int(peaks_int), int(bool(verbose)), cap, rows,
+        ctypes.byref(n_rows), ctypes.byref(chosen))
+    if st == _native.ERROR_SEARCH_TOO_MANY_PEAKS:
+        raise ValueError(_native.last_error())
+    if st != 0:
+        bg = os.path.realpath(os.path.join(problem_dir, "coverage.bedGraph"))
+        pen = rows[n_rows.value].penalty_str.decode() if n_rows.value < cap else ""
+        msg = _native.status_message(st, bg, pen, "%s_penalty=%s.db" % (bg, pen))
+        detail = _native.last_error()
+        if st >= _native.ERROR_NO_HIP_DEVICE and detail:
+            msg = "%s (%s)" % (msg, detail)
+        raise PeakSegError(st, msg)
     model_list = {}
-    next_pen = [0.0, float("inf")]
-    iteration = 0
-    under_peaks = over_peaks = None  # data.table(peaks=NA)
-    under = over = candidate = None
-
-    def row(model):
-        return model.loss.iloc[0]
-
-    while next_pen is not None and len(next_pen):
-        if verbose:
-            print("Next =", ", ".join(paste(p) for p in next_pen))
-        next_str = [paste(p) for p in next_pen]
-        iteration += 1
-        for penalty_str in next_str:
-            L = PeakSegFPOP_dir(problem_dir, penalty_str)
-            L.loss["iteration"] = iteration
-            L.loss["under"] = np.nan if under_peaks is None else under_peaks
-            L.loss["over"] = np.nan if over_peaks is None else over_peaks
-            model_list[penalty_str] = L
-        if iteration == 1:
-            under = row(model_list["Inf"])
-            over = row(model_list["0"])
-            max_peaks = math.floor((over["bases"] - 1) / 2)
-            if max_peaks < peaks_int:
-                raise ValueError("peaks.int=%d but max=%d peaks for N=%d data"
-                                 % (peaks_int, max_peaks, over["bases"]))
-        else:
-            Mnew = row(model_list[next_str[0]])
-            if Mnew["peaks"] in (under["peaks"], over["peaks"]):  # not a new model
-                candidate = under
-                next_pen = None
-            elif Mnew["peaks"] < peaks_int:
-                under = Mnew
-            else:
-                over = Mnew
-        under_peaks, over_peaks = under["peaks"], over["peaks"]
-        if peaks_int == under["peaks"]:
-            candidate = under
-            next_pen = None
-        if peaks_int == over["peaks"]:
-            candidate = over
-            next_pen = None
-        if next_pen is not None:
-            pen = (over["total.loss"] - under["total.loss"]) / (under["peaks"] - over["peaks"])
-            if pen < 0:
-                candidate = under
-                next_pen = None
-            else:
-                next_pen = [pen]
-    out = model_list[paste(float(candidate["penalty"]))]
+    for k in range(n_rows.value):
+        r = rows[k]
+        pen_str = r.penalty_str.decode()
+        L = PeakSegFPOP_dir(problem_dir, pen_str)  # the files of this model (cache hit)
+        L.loss["iteration"] = r.iteration
+        L.loss["under"] = np.nan if r.under_peaks == _native.SEARCH_NA else r.under_peaks
+        L.loss["over"] = np.nan if r.over_peaks == _native.SEARCH_NA else r.over_peaks
+        model_list[pen_str] = L
+    out = model_list[rows[chosen.value].penalty_str.decode()]
     others = pd.concat([m.loss for m in model_list.values()], ignore_index=True)
     out.others = others.sort_values("iteration", kind="stable").reset_index(drop=True)
     return out

@@ -28,6 +28,7 @@
 namespace psd {
 namespace PSD_VARIANT {
 
+/* lists / scratch of spill-pool slot p (a problem's slot, see take_spill_slot) */
 PSD_D GlobalList global_list(const DeviceArgs &a, int p, int id) {
   const size_t cap = (size_t)a.spill_cap;
   double *f = a.spill_f64 + ((size_t)p * 48 + (size_t)id * 6) * cap;
@@ -73,14 +74,21 @@ struct ArenaCursor {
   int used, room;
 };
 
-/* Take the next run of arena chunks for this wave (cold: once per 65536 pieces).  Returns the
- * first chunk index; ~0 when the arena is exhausted. */
-PSD_COLD_DEV unsigned long long arena_take_chunks(const DeviceArgs &a, int chunks) {
+/* Reserve arena room for a function of n pieces: the next run of whole chunks for this wave
+ * (cold: once per chunk of 2^ar_chunk_log2 pieces).  Returns the first piece index of the run;
+ * ~0 when the arena is exhausted. */
+PSD_COLD_DEV unsigned long long arena_take(const DeviceArgs &a, int n) {
+  const int lg = a.ar_chunk_log2;
+  const unsigned long long chunks = ((unsigned long long)uniform_i(n) + (1ull << lg) - 1ull) >> lg;
   unsigned long long first = 0;
-  if (lane_id() == 0) first = atomicAdd(a.ar_next_chunk, (unsigned long long)chunks);
+  if (lane_id() == 0) first = atomicAdd(a.ar_next_chunk, chunks);
   first = psd_d2u(rdlane_d(psd_u2d(first), 0));
-  if (((first + (unsigned long long)chunks) << ARENA_CHUNK_LOG2) > a.ar_cap) return ~0ull;
-  return first;
+  if (((first + chunks) << lg) > a.ar_cap) return ~0ull;
+  return first << lg;
+}
+PSD_D int arena_room_for(const DeviceArgs &a, int n) {
+  const int lg = a.ar_chunk_log2;
+  return (int)((((unsigned)n + (1u << lg) - 1u) >> lg) << lg);
 }
 
 /* Append one function's backtrack record to the arena; returns false when it is full. */
@@ -89,12 +97,11 @@ PSD_D bool arena_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &f, i
                             unsigned long long fn_index) {
   const int lane = lane_id();
   if (n > cur.room - cur.used) {
-    int chunks = (n + ARENA_CHUNK - 1) >> ARENA_CHUNK_LOG2;
-    unsigned long long first = psd_d2u(uniform_d(psd_u2d(arena_take_chunks(a, chunks))));
-    if (first == ~0ull) return false;
-    cur.base = first << ARENA_CHUNK_LOG2;
+    unsigned long long base = psd_d2u(uniform_d(psd_u2d(arena_take(a, n))));
+    if (base == ~0ull) return false;
+    cur.base = base;
     cur.used = 0;
-    cur.room = chunks << ARENA_CHUNK_LOG2;
+    cur.room = arena_room_for(a, n);
   }
   unsigned long long off = cur.base + (unsigned long long)cur.used;
   for (int base = 0; base < n; base += WAVE) {
@@ -121,15 +128,14 @@ PSD_D bool scale_add_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &
   const int lane = lane_id();
   bool ok = true;
   if (store && n > cur.room - cur.used) {
-    int chunks = (n + ARENA_CHUNK - 1) >> ARENA_CHUNK_LOG2;
-    unsigned long long first = psd_d2u(uniform_d(psd_u2d(arena_take_chunks(a, chunks))));
-    if (first == ~0ull) {
+    unsigned long long base = psd_d2u(uniform_d(psd_u2d(arena_take(a, n))));
+    if (base == ~0ull) {
       ok = false;
       store = false;
     } else {
-      cur.base = first << ARENA_CHUNK_LOG2;
+      cur.base = base;
       cur.used = 0;
-      cur.room = chunks << ARENA_CHUNK_LOG2;
+      cur.room = arena_room_for(a, n);
     }
   }
   const unsigned long long off = cur.base + (unsigned long long)cur.used;
@@ -306,8 +312,8 @@ PSD_D int chain_step_fast(const DeviceArgs &a, ArenaCursor &cur, unsigned long l
   return ok ? n_new : -WERR_ARENA;
 }
 
-/* Move one list between LDS and the HBM spill area (cold: only when a function outgrows LDS
- * or has shrunk again). */
+/* Move one list between LDS and the problem's slot p of the HBM spill pool (cold: only when a
+ * function outgrows LDS or has shrunk again). */
 PSD_COLD_DEV void move_list_hbm(const DeviceArgs &a, int p, int id, int n, int to_hbm) {
   p = uniform_i(p);
   id = uniform_i(id);
@@ -473,6 +479,19 @@ constexpr int FORWARD_THREADS = 128;
 PSD_D void block_sync(int) { __syncthreads(); }
 #endif
 
+/* Take a slot of the HBM spill pool for this workgroup's problem (cold: at most once per
+ * problem).  Both chain waves call it; returns the slot, or -1 when the pool is exhausted. */
+PSD_COLD_DEV int take_spill_slot(const DeviceArgs &a, int chain) {
+  chain = uniform_i(chain);
+  if (chain == 0 && lane_id() == 0) {
+    int sl = atomicAdd(a.spill_next, 1);
+    g_sm.spill_slot = sl < a.spill_slots ? sl : -1;
+  }
+  block_sync(chain);
+  return uniform_i(g_sm.spill_slot);
+}
+
+
 /* PSD_KERNEL_WAVES_PER_EU (throughput build): keep the kernel's own register use within the
  * budget of that many waves per SIMD, as the out-of-line operations already are */
 #undef PSD_KERNEL_OCC
@@ -536,6 +555,7 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
   int cnt_reg = 0, wt_reg = 0;
   int b = 0;        /* buffer holding step t-1 */
   bool in_hbm = false; /* where the lists of step t-1 live */
+  int spill_slot = -1; /* this problem's slot of the HBM spill pool, taken on first overflow */
   int t = 0;
   unsigned sync_no = 0; /* parity slot of the abort flags: one per barrier */
 #ifdef PSD_PROFILE
@@ -558,7 +578,7 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
     const int n_other = uniform_i(g_sm.n[id_other_prev]);
     /* come back from HBM when both functions fit comfortably again */
     if (in_hbm && n_own <= LDS_CAP / 2 && n_other <= LDS_CAP / 2) {
-      move_list_hbm(a, p, id_own_prev, n_own, 0);
+      move_list_hbm(a, spill_slot, id_own_prev, n_own, 0);
       in_hbm = false;
       block_sync(chain);
     }
@@ -594,7 +614,7 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
 #endif
       } else {
         ArenaCursor cur_hbm = cur; /* only this copy has its address taken */
-        n_new = uniform_i(chain_step_hbm(a, cur_hbm, fn0 + (unsigned long long)t, p, chain, t,
+        n_new = uniform_i(chain_step_hbm(a, cur_hbm, fn0 + (unsigned long long)t, spill_slot, chain, t,
                                id_other_prev, n_other, id_own_prev, n_own, id_own_new,
                                penalty / cum_weight_prev_i, cum_weight_prev_i, w, coverage,
                                cum_weight_new));
@@ -621,7 +641,14 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
       sync_no++;
       if (status == PST_LDS_OVERFLOW && !in_hbm && a.spill_cap > LDS_CAP && t > 0) {
         /* redo this data point with the lists in HBM: every wave moves its own t-1 list */
-        move_list_hbm(a, p, id_own_prev, n_own, 1);
+        if (spill_slot < 0) {
+          spill_slot = take_spill_slot(a, chain);
+          if (spill_slot < 0) {
+            status = PST_SPILL_FULL;
+            break;
+          }
+        }
+        move_list_hbm(a, spill_slot, id_own_prev, n_own, 1);
         in_hbm = true;
         status = 0;
         block_sync(chain);
@@ -673,7 +700,7 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
     if (status == 0) {
       const int id = 2 + b;
       if (in_hbm) {
-        minimize_wave(global_list(a, p, id), g_sm.n[id], &r.best_cost, &r.best_log_mean,
+        minimize_wave(global_list(a, spill_slot, id), g_sm.n[id], &r.best_cost, &r.best_log_mean,
                       &r.prev_seg_end, &r.prev_log_mean);
       } else {
         minimize_wave(lds_list(id), g_sm.n[id], &r.best_cost, &r.best_log_mean, &r.prev_seg_end,

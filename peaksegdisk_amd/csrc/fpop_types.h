@@ -8,9 +8,15 @@ namespace psd {
 
 constexpr int N_PROF = 24; /* PSD_PROFILE builds: cycle counters per wave */
 
-constexpr int ARENA_CHUNK_LOG2 = 16;  /* arena is handed out in chunks of 65536 pieces */
-constexpr int ARENA_CHUNK = 1 << ARENA_CHUNK_LOG2;
+/* The arena is handed out in chunks of 2^ar_chunk_log2 pieces (one global atomic per chunk, one
+ * cursor per wave).  The host picks the chunk size per problem set: 65536 pieces for long
+ * contigs, down to 1024 for sets of many short problems, so that the unused tail of each
+ * wave's last chunk stays a small fraction of the arena. */
+constexpr int ARENA_CHUNK_LOG2_MAX = 16;
+constexpr int ARENA_CHUNK_LOG2_MIN = 10;
 constexpr int FN_COUNT_BITS = 24;     /* fn_ref = (arena offset << 24) | piece count */
+/* merged-interval table entries pack (piece of f1 << 16) | piece of f2 into an int */
+constexpr int SPILL_CAP_MAX = 32767;
 
 /* problem status written by the kernels (0 = ok) */
 enum {
@@ -19,6 +25,7 @@ enum {
   PST_ARENA_FULL = 2,    /* host retries with a larger arena */
   PST_REF_THROW = 3,     /* the reference would throw / loop / read a list sentinel */
   PST_BACKTRACK = 4,     /* findMean found no piece (the reference would never return) */
+  PST_SPILL_FULL = 5,    /* no free slot in the HBM spill pool: host retries with more slots */
 };
 
 struct ProbResult {
@@ -58,17 +65,21 @@ struct DeviceArgs {
   double *ar_prv;
   int *ar_di;
   unsigned long long ar_cap; /* pieces */
+  int ar_chunk_log2;
   unsigned long long *ar_next_chunk;
   unsigned long long *fn_ref;
   /* segment tables, in backtrack order */
   int *seg_start;   /* data index whose chromEnd starts the segment; -1 = first_chromStart */
   double *seg_mean; /* exp(best_log_mean) */
   long long *prof;  /* PSD_PROFILE builds: per (problem, wave) cycle counters, else NULL */
-  /* spill area for functions with more than LDS_CAP pieces: per problem 48*spill_cap doubles
-   * (6 lists x 6 fields + 2 waves x 6 scratch arrays) and 12*spill_cap ints */
+  /* spill pool for functions with more than LDS_CAP pieces: spill_slots slots of 48*spill_cap
+   * doubles (6 lists x 6 fields + 2 waves x 6 scratch arrays) and 12*spill_cap ints; a problem
+   * takes a slot (spill_next, one atomic) the first time one of its functions outgrows LDS */
   double *spill_f64;
   int *spill_i32;
   int spill_cap;
+  int spill_slots;
+  int *spill_next;
 };
 
 }  // namespace psd

@@ -90,6 +90,7 @@ struct SharedBlock {
   unsigned long long total_up;
   int max_up;
   int serial[2];
+  int spill_slot; /* slot of the HBM spill pool taken by this problem (take_spill_slot) */
 #ifdef PSD_HELPER_WAVES
   Mail mail[2];
 #endif
@@ -1738,7 +1739,8 @@ PSD_D int min_env_impl(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, i
     }
     K = n1 + n2 - dup_total;
   }
-  if (K > iv_cap || n1 >= 65536 || n2 >= 65536) return -WERR_OVERFLOW;
+  /* (i1 << 16) | i2 in a signed int: both indices stay below 32768 (SPILL_CAP_MAX) */
+  if (K > iv_cap || n1 > SPILL_CAP_MAX || n2 > SPILL_CAP_MAX) return -WERR_OVERFLOW;
   wave_sync();
   PSD_PROF_ADD(PROF_TABLE);
 

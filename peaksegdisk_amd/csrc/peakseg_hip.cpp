@@ -259,6 +259,10 @@ struct psd_problem_set {
   long long total_bins = 0, fn_total = 0, seg_total = 0;
   unsigned long long arena_pieces = 0;
   bool arena_auto = true;
+  unsigned long long max_bytes = 0;   /* PEAKSEG_HIP_MAX_BYTES (0 = no cap besides free HBM) */
+  unsigned long long arena_used = 0;  /* pieces handed out by the last solve */
+  long long dp_bins = 0;
+  int spill_slots = 0;
   psd::DeviceArgs d{};
   hipStream_t stream = nullptr;
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -315,18 +319,98 @@ void free_arena(psd_problem_set *s) {
   s->d.ar_cap = 0;
 }
 
+unsigned long long env_bytes(const char *name) {
+  const char *e = getenv(name);
+  if (!e || !*e) return 0;
+  char *end = nullptr;
+  double v = strtod(e, &end);
+  if (end == e || !(v > 0)) return 0;
+  switch (*end) { /* optional K/M/G/T suffix */
+    case 'k': case 'K': v *= 1024.0; break;
+    case 'm': case 'M': v *= 1024.0 * 1024.0; break;
+    case 'g': case 'G': v *= 1024.0 * 1024.0 * 1024.0; break;
+    case 't': case 'T': v *= 1024.0 * 1024.0 * 1024.0 * 1024.0; break;
+    default: break;
+  }
+  return (unsigned long long)v;
+}
+
+/* How many arena pieces may still be allocated: what the device has free (a tenth is left for
+ * other processes sharing the GPU -- R's future workers are separate processes on one device,
+ * SURVEY.md section 8b "Threading") and what PEAKSEG_HIP_MAX_BYTES leaves of this set's budget. */
+unsigned long long arena_fit(psd_problem_set *s) {
+  unsigned long long fit = ~0ull;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) fit = (unsigned long long)(free_b * 0.9) / 20ull;
+  if (s->max_bytes) {
+    unsigned long long room = s->max_bytes > s->bytes ? (s->max_bytes - s->bytes) / 20ull : 0ull;
+    if (room < fit) fit = room;
+  }
+  return fit;
+}
+
 int alloc_arena(psd_problem_set *s, unsigned long long pieces) {
-  /* whole chunks, and at least two per problem wave so that nobody starves at start-up */
-  unsigned long long min_pieces =
-      (unsigned long long)psd::ARENA_CHUNK * 2ull * (unsigned long long)s->n_problems;
+  /* chunk size: about a sixteenth of what one wave will store, within [2^10, 2^16] pieces */
+  const unsigned long long n_waves = 2ull * (unsigned long long)s->n_problems;
+  int lg = psd::ARENA_CHUNK_LOG2_MIN;
+  while (lg < psd::ARENA_CHUNK_LOG2_MAX && (pieces / n_waves) >> (lg + 5)) lg++;
+  const unsigned long long chunk = 1ull << lg;
+  /* whole chunks, and at least two per wave so that nobody starves at start-up */
+  unsigned long long min_pieces = chunk * 2ull * n_waves;
   if (pieces < min_pieces) pieces = min_pieces;
-  pieces = (pieces + psd::ARENA_CHUNK - 1) / psd::ARENA_CHUNK * psd::ARENA_CHUNK;
+  pieces = (pieces + chunk - 1) / chunk * chunk;
   int st;
   if ((st = dev_alloc(s, &s->d.ar_mx, pieces))) return st;
   if ((st = dev_alloc(s, &s->d.ar_prv, pieces))) return st;
   if ((st = dev_alloc(s, &s->d.ar_di, pieces))) return st;
   s->d.ar_cap = pieces;
+  s->d.ar_chunk_log2 = lg;
   s->arena_pieces = pieces;
+  return 0;
+}
+
+void free_spill(psd_problem_set *s) {
+  void *ptrs[2] = {s->d.spill_f64, s->d.spill_i32};
+  for (void *q : ptrs) {
+    if (!q) continue;
+    for (size_t i = 0; i < s->allocs.size(); i++) {
+      if (s->allocs[i] == q) {
+        s->allocs.erase(s->allocs.begin() + (long)i);
+        break;
+      }
+    }
+    (void)hipFree(q);
+  }
+  s->bytes -= (unsigned long long)s->spill_slots * (unsigned long long)s->d.spill_cap * (48ull * 8 + 12ull * 4);
+  s->d.spill_f64 = nullptr;
+  s->d.spill_i32 = nullptr;
+  s->spill_slots = 0;
+  s->d.spill_slots = 0;
+}
+
+/* Pool of HBM spill slots for problems whose functions outgrow LDS (adversarial data): 432
+ * bytes per piece of capacity per slot; a problem takes a slot on its first overflow. */
+int alloc_spill(psd_problem_set *s, int slots) {
+  if (slots > s->n_problems) slots = s->n_problems;
+  if (slots < 1) slots = 1;
+  const size_t cap = (size_t)s->d.spill_cap;
+  int st;
+  if (cap == 0) return 0;
+  if ((st = dev_alloc(s, &s->d.spill_f64, (size_t)slots * 48 * cap)) ||
+      (st = dev_alloc(s, &s->d.spill_i32, (size_t)slots * 12 * cap)))
+    return st;
+  s->spill_slots = slots;
+  s->d.spill_slots = slots;
+  return 0;
+}
+
+int env_device() {
+  /* which GPU the file-level entry points use: PEAKSEG_HIP_DEVICE (one process per GPU sets it
+   * from its rank); default 0 */
+  if (const char *e = getenv("PEAKSEG_HIP_DEVICE")) {
+    int d = atoi(e);
+    if (d >= 0) return d;
+  }
   return 0;
 }
 
@@ -357,6 +441,23 @@ extern "C" const char *peakseg_hip_problem_set_kernel_build(psd_problem_set *s) 
 
 extern "C" unsigned long long peakseg_hip_problem_set_bytes(psd_problem_set *s) {
   return s ? s->bytes : 0;
+}
+
+extern "C" unsigned long long peakseg_hip_problem_set_arena_bytes_used(psd_problem_set *s) {
+  return s ? s->arena_used * 20ull : 0;
+}
+
+extern "C" int peakseg_hip_problem_set_set_penalty(psd_problem_set *s, int p, double penalty) {
+  if (!s || p < 0 || p >= s->n_problems) return -1;
+  if (hipSetDevice(s->device) != hipSuccess) return -1;
+  s->prob_penalty[(size_t)p] = penalty;
+  if (hipMemcpy(const_cast<double *>(s->d.prob_penalty) + p, &penalty, sizeof(double),
+                hipMemcpyHostToDevice) != hipSuccess) {
+    set_error("penalty upload failed");
+    return -1;
+  }
+  s->solved = false;
+  return 0;
 }
 
 extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const int *contig_n_bins,
@@ -423,6 +524,8 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
   }
   s->fn_total = fn_off;
   s->seg_total = seg_off;
+  s->dp_bins = dp_bins;
+  s->max_bytes = env_bytes("PEAKSEG_HIP_MAX_BYTES");
   /* workgroups are dispatched in index order: start the longest problems first so that a
    * set of unequal contigs does not end with one long problem running alone */
   std::vector<int> order((size_t)n_problems);
@@ -446,24 +549,28 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
       (st = dev_upload(s, &d.count, count)) || (st = dev_upload(s, &d.weight, weight)) ||
       (st = dev_alloc(s, &d.result, (size_t)n_problems)) ||
       (st = dev_alloc(s, &d.ar_next_chunk, (size_t)1)) ||
+      (st = dev_alloc(s, &d.spill_next, (size_t)1)) ||
       (st = dev_alloc(s, &d.fn_ref, (size_t)fn_off)) ||
       (st = dev_alloc(s, &d.seg_start, (size_t)seg_off)) ||
       (st = dev_alloc(s, &d.seg_mean, (size_t)seg_off))) {
     peakseg_hip_problem_set_destroy(s);
     return st;
   }
-  /* spill area for functions that outgrow LDS (adversarial data): PEAKSEG_HIP_SPILL_CAP pieces
-   * per list, default 16384 (432 bytes per piece per problem); 0 disables spilling */
+  /* spill pool for functions that outgrow LDS (adversarial data): PEAKSEG_HIP_SPILL_CAP pieces
+   * per list (default 16384, at most 32767: the interval table packs two indices into an int;
+   * 0 disables spilling), PEAKSEG_HIP_SPILL_SLOTS slots to start with (default 16; the pool is
+   * grown and the set rerun when more problems spill at once) */
   {
     int cap = 16384;
     if (const char *e = getenv("PEAKSEG_HIP_SPILL_CAP")) cap = atoi(e);
-    if (cap > 65535) cap = 65535;
+    if (cap > psd::SPILL_CAP_MAX) cap = psd::SPILL_CAP_MAX;
     if (cap <= psd::lat::LDS_CAP) cap = 0;
     d.spill_cap = cap;
     d.spill_f64 = nullptr;
     d.spill_i32 = nullptr;
-    if (cap > 0 && ((st = dev_alloc(s, &d.spill_f64, (size_t)n_problems * 48 * (size_t)cap)) ||
-                    (st = dev_alloc(s, &d.spill_i32, (size_t)n_problems * 12 * (size_t)cap)))) {
+    int slots = 16;
+    if (const char *e = getenv("PEAKSEG_HIP_SPILL_SLOTS")) slots = atoi(e);
+    if ((st = alloc_spill(s, slots))) {
       peakseg_hip_problem_set_destroy(s);
       return st;
     }
@@ -476,17 +583,28 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
 #else
   d.prof = nullptr;
 #endif
-  /* arena: the reference's store holds 2 functions per data point with, on typical
-   * coverage data, 2-14 pieces each; start at 24 per function and let
-   * solve() grow it if a problem reports PST_ARENA_FULL. */
+  /* arena: the reference's store holds 2 functions per data point with, on typical coverage
+   * data, 2-14 pieces each.  Sized from that estimate
+   * (PEAKSEG_HIP_PIECES_PER_FUNCTION, default 16), never beyond nine tenths of what is free on
+   * the device or what PEAKSEG_HIP_MAX_BYTES allows; solve() doubles it and reruns if a problem
+   * reports PST_ARENA_FULL. */
   s->arena_auto = arena_pieces == 0;
-  unsigned long long want = arena_pieces ? arena_pieces : (unsigned long long)dp_bins * 2ull * 24ull;
+  unsigned long long want = arena_pieces;
   if (s->arena_auto) {
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-      unsigned long long fit = (unsigned long long)(free_b * 0.9) / 20ull;
-      if (want > fit) want = fit;
+    double per_fn = 16.0;
+    if (const char *e = getenv("PEAKSEG_HIP_PIECES_PER_FUNCTION")) {
+      double v = atof(e);
+      if (v >= 1.0) per_fn = v;
     }
+    want = (unsigned long long)((double)dp_bins * 2.0 * per_fn);
+    unsigned long long fit = arena_fit(s);
+    if (want > fit) want = fit;
+  }
+  if (s->max_bytes && s->bytes + want * 20ull > s->max_bytes) {
+    set_error("problem set needs %llu bytes, PEAKSEG_HIP_MAX_BYTES allows %llu",
+              s->bytes + want * 20ull, s->max_bytes);
+    peakseg_hip_problem_set_destroy(s);
+    return ERROR_DEVICE_MEMORY;
   }
   if ((st = alloc_arena(s, want))) {
     peakseg_hip_problem_set_destroy(s);
@@ -522,6 +640,7 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
   }
   for (int attempt = 0;; attempt++) {
     HIP_TRY(hipMemsetAsync(s->d.ar_next_chunk, 0, sizeof(unsigned long long), s->stream));
+    HIP_TRY(hipMemsetAsync(s->d.spill_next, 0, sizeof(int), s->stream));
     HIP_TRY(hipEventRecord(s->ev[0], s->stream));
     if (s->throughput)
       hipLaunchKernelGGL(psd::thr::fpop_forward_kernel, dim3((unsigned)s->n_problems),
@@ -538,27 +657,53 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
     if (backtrack_ms) *backtrack_ms = 0.f; /* decoding happens inside the forward kernel */
     HIP_TRY(hipMemcpy(s->results.data(), s->d.result,
                       sizeof(psd::ProbResult) * (size_t)s->n_problems, hipMemcpyDeviceToHost));
-    bool arena_full = false;
-    for (auto &r : s->results) arena_full = arena_full || r.status == psd::PST_ARENA_FULL;
-    if (!arena_full) break;
-    if (!s->arena_auto || attempt >= 4) {
-      set_error("cost-function arena of %llu pieces is too small", s->arena_pieces);
+    {
+      unsigned long long chunks = 0;
+      HIP_TRY(hipMemcpy(&chunks, s->d.ar_next_chunk, sizeof chunks, hipMemcpyDeviceToHost));
+      s->arena_used = chunks << s->d.ar_chunk_log2;
+      if (s->arena_used > s->d.ar_cap) s->arena_used = s->d.ar_cap;
+    }
+    bool arena_full = false, spill_full = false;
+    for (auto &r : s->results) {
+      arena_full = arena_full || r.status == psd::PST_ARENA_FULL;
+      spill_full = spill_full || r.status == psd::PST_SPILL_FULL;
+    }
+    if (!arena_full && !spill_full) break;
+    if (attempt >= 6) {
+      set_error("cost-function arena (%llu pieces) / spill pool (%d slots) still too small after "
+                "%d reruns", s->arena_pieces, s->spill_slots, attempt);
       return ERROR_DEVICE_MEMORY;
     }
-    /* grow and rerun the whole set */
-    unsigned long long bigger = s->arena_pieces * 3ull;
-    free_arena(s);
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-      unsigned long long fit = (unsigned long long)(free_b * 0.9) / 20ull;
+    if (spill_full) {
+      /* more problems spilled at once than the pool has slots: four times the slots */
+      int slots = s->spill_slots * 4;
+      if (s->spill_slots >= s->n_problems) {
+        set_error("spill pool exhausted with one slot per problem");
+        return ERROR_DEVICE_SOLVER;
+      }
+      free_spill(s);
+      int st = alloc_spill(s, slots);
+      if (st) return st;
+    }
+    if (arena_full) {
+      if (!s->arena_auto) {
+        set_error("cost-function arena of %llu pieces is too small", s->arena_pieces);
+        return ERROR_DEVICE_MEMORY;
+      }
+      /* grow and rerun the whole set */
+      unsigned long long bigger = s->arena_pieces * 2ull;
+      unsigned long long old_pieces = s->arena_pieces;
+      free_arena(s);
+      unsigned long long fit = arena_fit(s);
       if (bigger > fit) bigger = fit;
+      if (bigger <= old_pieces) {
+        set_error("cost-function arena cannot grow beyond %llu pieces (free HBM / "
+                  "PEAKSEG_HIP_MAX_BYTES)", old_pieces);
+        return ERROR_DEVICE_MEMORY;
+      }
+      int st = alloc_arena(s, bigger);
+      if (st) return st;
     }
-    if (bigger <= s->arena_pieces) {
-      set_error("cost-function arena cannot grow beyond %llu pieces", s->arena_pieces);
-      return ERROR_DEVICE_MEMORY;
-    }
-    int st = alloc_arena(s, bigger);
-    if (st) return st;
   }
   s->solved = true;
   int first = 0;
@@ -731,272 +876,9 @@ extern "C" int peakseg_hip_math_probe(int op, int n, const double *x, double *y)
   return 0;
 }
 
-/* ---- file-level solver (the reference's boundary) ------------------------------------- */
-
-namespace {
-
-struct FileProblem {
-  const char *bedGraph, *penalty_str, *db;
-  int status = 0;
-  bool is_Inf = false;
-  double penalty = 0.0;
-  int cov = -1;     /* index into the parsed-coverage table */
-  int dp_index = -1; /* index into the device problem set, -1 = trivial/none */
-  FILE *loss_file = nullptr, *segments_file = nullptr;
-  bool loss_failed = false, segments_failed = false;
-};
-
-void out_printf(FILE *f, bool &failed, const char *fmt, ...) {
-  if (!f) return;
-  va_list ap;
-  va_start(ap, fmt);
-  if (vfprintf(f, fmt, ap) < 0) failed = true;
-  va_end(ap);
-}
-
-void close_outputs(FileProblem &fp) {
-  if (fp.loss_file) {
-    if (fclose(fp.loss_file) != 0) fp.loss_failed = true;
-    fp.loss_file = nullptr;
-  }
-  if (fp.segments_file) {
-    if (fclose(fp.segments_file) != 0) fp.segments_failed = true;
-    fp.segments_file = nullptr;
-  }
-}
-
-/* trivial one-segment model (drv:224-243) */
-void write_trivial(FileProblem &fp, const Coverage &cv) {
-  double best_cost;
-  if (cv.cum_weighted_count != 0) {
-    best_cost =
-        cv.cum_weighted_count * (1 - psd_log(cv.cum_weighted_count) + psd_log(cv.cum_weight));
-  } else {
-    best_cost = 0;
-  }
-  out_printf(fp.segments_file, fp.segments_failed, "%s\t%d\t%d\tbackground\t%g\n",
-             cv.chrom.c_str(), cv.first_chromStart, cv.chromEnd.back(),
-             cv.cum_weighted_count / cv.cum_weight);
-  out_printf(fp.loss_file, fp.loss_failed, "%s\t%d\t%d\t%d\t%d\t%.20g\t%.20g\t%d\t%d\t%d\n",
-             fp.penalty_str, 1, 0, (int)cv.cum_weight, cv.n(), best_cost / cv.cum_weight, best_cost,
-             0, 0, 0);
-}
-
-/* one problem's results, copied off the device */
-struct DpFetched {
-  int status = 0;
-  psd_result r{};
-  std::vector<int> seg_start;
-  std::vector<double> seg_mean;
-};
-
-void fetch_dp(const FileProblem &fp, psd_problem_set *set, DpFetched &f) {
-  if (peakseg_hip_problem_set_result(set, fp.dp_index, &f.r) != 0 || f.r.status != 0) {
-    f.status = ERROR_DEVICE_SOLVER;
-    return;
-  }
-  f.seg_start.resize((size_t)f.r.n_segments);
-  f.seg_mean.resize((size_t)f.r.n_segments);
-  if (peakseg_hip_problem_set_segments(set, fp.dp_index, f.r.n_segments, f.seg_start.data(),
-                                       f.seg_mean.data()) != f.r.n_segments)
-    f.status = ERROR_DEVICE_SOLVER;
-}
-
-/* the DP branch's two files (drv:419-454) */
-int write_dp_outputs(FileProblem &fp, const Coverage &cv, const DpFetched &f) {
-  if (f.status) return f.status;
-  const psd_result &r = f.r;
-  int prev_chromEnd = cv.chromEnd.back();
-  const char *chrom = cv.chrom.c_str();
-  for (int row = 0; row < r.n_segments; row++) {
-    int start = f.seg_start[(size_t)row] < 0 ? cv.first_chromStart
-                                             : cv.chromEnd[(size_t)f.seg_start[(size_t)row]];
-    /* rows alternate background/peak starting and ending with background (drv:421-429,442) */
-    const char *status_str = (row % 2 == 0) ? "background" : "peak";
-    out_printf(fp.segments_file, fp.segments_failed, "%s\t%d\t%d\t%s\t%g\n", chrom, start,
-               prev_chromEnd, status_str, f.seg_mean[(size_t)row]);
-    prev_chromEnd = start;
-  }
-  int n_peaks = (r.n_segments - 1) / 2;
-  double total_intervals = (double)r.total_intervals;
-  out_printf(fp.loss_file, fp.loss_failed,
-             "%.20g\t%d\t%d\t%d\t%d\t%.20g\t%.20g\t%d\t%.20g\t%.20g\n", fp.penalty,
-             r.n_segments, n_peaks, (int)cv.cum_weight, cv.n(), r.best_cost,
-             r.best_cost * cv.cum_weight - fp.penalty * n_peaks, r.n_equality_constraints,
-             total_intervals / (cv.n() * 2), (double)r.max_intervals);
-  /* leave a sparse file of the size the reference's DiskVector would have:
-   * 2N 16-byte positions + per function {int size, int n, int chromEnd} + 20 B per piece */
-  long long db_size = 32ll * cv.n() + 12ll * (2ll * cv.n() - 1) + 20ll * (long long)r.total_intervals;
-  if (truncate(fp.db, (off_t)db_size) != 0) return ERROR_WRITING_COST_FUNCTIONS;
-  return 0;
-}
-
-double wall_now() {
-  struct timespec ts;
-  clock_gettime(CLOCK_MONOTONIC, &ts);
-  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
-}
-
-int solve_files(int n, FileProblem *fps) {
-  /* PEAKSEG_HIP_TIMING=1: where a call spends its time, on stderr */
-  const bool timing = getenv("PEAKSEG_HIP_TIMING") != nullptr;
-  double t_mark = wall_now();
-  auto lap = [&](const char *what) {
-    if (!timing) return;
-    double now = wall_now();
-    fprintf(stderr, "peakseg_hip timing: %-28s %8.3f s\n", what, now - t_mark);
-    t_mark = now;
-  };
-  std::vector<Coverage> covs;
-  std::map<std::string, int> cov_of_path;
-  std::map<std::string, int> cov_status;
-  /* 1. penalties, then inputs (validation order of drv:145-209) */
-  for (int i = 0; i < n; i++) {
-    FileProblem &fp = fps[i];
-    fp.status = parse_penalty(fp.penalty_str, fp.is_Inf, fp.penalty);
-    if (fp.status) continue;
-    std::string path = fp.bedGraph;
-    auto it = cov_of_path.find(path);
-    if (it == cov_of_path.end()) {
-      Coverage cv;
-      int st = read_bedGraph(fp.bedGraph, cv);
-      covs.push_back(std::move(cv));
-      int idx = (int)covs.size() - 1;
-      cov_of_path[path] = idx;
-      cov_status[path] = st;
-      it = cov_of_path.find(path);
-    }
-    fp.cov = it->second;
-    fp.status = cov_status[path];
-  }
-  lap("parse bedGraph");
-  /* 2. output files are opened before the trivial/DP split (drv:212-223); the db is only
-   *    touched in the DP branch (drv:247-252) */
-  std::vector<int> dp;
-  for (int i = 0; i < n; i++) {
-    FileProblem &fp = fps[i];
-    if (fp.status) continue;
-    const Coverage &cv = covs[(size_t)fp.cov];
-    std::string pre = std::string(fp.bedGraph) + "_penalty=" + fp.penalty_str;
-    fp.loss_file = fopen((pre + "_loss.tsv").c_str(), "w");
-    fp.segments_file = fopen((pre + "_segments.bed").c_str(), "w");
-    fp.loss_failed = fp.loss_file == nullptr;
-    fp.segments_failed = fp.segments_file == nullptr;
-    if (fp.is_Inf || cv.min_log_mean == cv.max_log_mean) {
-      write_trivial(fp, cv);
-    } else {
-      FILE *db = fopen(fp.db, "w+b");
-      if (!db) {
-        fp.status = ERROR_WRITING_COST_FUNCTIONS;
-        close_outputs(fp);
-        continue;
-      }
-      fclose(db);
-      dp.push_back(i);
-    }
-  }
-  /* 3. all dynamic programs in one device problem set */
-  if (!dp.empty()) {
-    std::vector<int> used_cov, contig_of_cov(covs.size(), -1);
-    std::vector<int> contig_n, prob_contig;
-    std::vector<const int *> cnt_ptr, wt_ptr;
-    std::vector<double> prob_pen;
-    for (int i : dp) {
-      FileProblem &fp = fps[i];
-      if (contig_of_cov[(size_t)fp.cov] < 0) {
-        contig_of_cov[(size_t)fp.cov] = (int)contig_n.size();
-        const Coverage &cv = covs[(size_t)fp.cov];
-        contig_n.push_back(cv.n());
-        cnt_ptr.push_back(cv.count.data());
-        wt_ptr.push_back(cv.weight.data());
-      }
-      fp.dp_index = (int)prob_contig.size();
-      prob_contig.push_back(contig_of_cov[(size_t)fp.cov]);
-      prob_pen.push_back(fp.penalty);
-    }
-    psd_problem_set *set = nullptr;
-    int st = peakseg_hip_problem_set_create(0, (int)contig_n.size(), contig_n.data(),
-                                            cnt_ptr.data(), wt_ptr.data(), (int)prob_contig.size(),
-                                            prob_contig.data(), prob_pen.data(), 0, &set);
-    lap("upload + allocate");
-    if (st == 0) {
-      st = peakseg_hip_problem_set_solve(set, nullptr, nullptr);
-      if (st == ERROR_DEVICE_SOLVER) st = 0; /* per-problem statuses decide below */
-    }
-    lap("kernel");
-    /* results leave the device one problem after the other; the text files (the segment
-     * tables of a penalty grid are hundreds of MB) are then formatted by a few threads */
-    std::vector<DpFetched> fetched(dp.size());
-    for (size_t k = 0; k < dp.size(); k++) {
-      if (st) {
-        fetched[k].status = st;
-      } else {
-        fetch_dp(fps[dp[k]], set, fetched[k]);
-      }
-    }
-    peakseg_hip_problem_set_destroy(set);
-    lap("download results + free");
-    std::atomic<size_t> next_k{0};
-    auto writer = [&]() {
-      for (size_t k = next_k++; k < dp.size(); k = next_k++) {
-        FileProblem &fp = fps[dp[k]];
-        fp.status = write_dp_outputs(fp, covs[(size_t)fp.cov], fetched[k]);
-      }
-    };
-    unsigned n_threads = std::thread::hardware_concurrency();
-    if (n_threads > 16) n_threads = 16;
-    if (n_threads > dp.size()) n_threads = (unsigned)dp.size();
-    if (n_threads <= 1) {
-      writer();
-    } else {
-      std::vector<std::thread> pool;
-      for (unsigned w = 0; w < n_threads; w++) pool.emplace_back(writer);
-      for (auto &th : pool) th.join();
-    }
-    lap("write segments/loss files");
-  }
-  /* 4. close, report write failures (drv:456-461: loss first) */
-  int first = 0;
-  for (int i = 0; i < n; i++) {
-    FileProblem &fp = fps[i];
-    bool had_outputs = fp.loss_file || fp.segments_file || fp.loss_failed || fp.segments_failed;
-    close_outputs(fp);
-    if (fp.status == 0 && had_outputs) {
-      if (fp.loss_failed) {
-        fp.status = ERROR_WRITING_LOSS_OUTPUT;
-      } else if (fp.segments_failed) {
-        fp.status = ERROR_WRITING_SEGMENTS_OUTPUT;
-      }
-    }
-    if (fp.status && !first) first = fp.status;
-  }
-  return first;
-}
-
-}  // namespace
-
-extern "C" int PeakSegFPOP_disk(char *bedGraph_file_name, char *penalty_str, char *db_file_name) {
-  FileProblem fp;
-  fp.bedGraph = bedGraph_file_name;
-  fp.penalty_str = penalty_str;
-  fp.db = db_file_name;
-  return solve_files(1, &fp);
-}
-
-extern "C" int PeakSegFPOP_disk_batch(int n_problems, char **bedGraph_files, char **penalty_strs,
-                                      char **db_files, int *status_out) {
-  if (n_problems <= 0) return 0;
-  std::vector<FileProblem> fps((size_t)n_problems);
-  for (int i = 0; i < n_problems; i++) {
-    fps[(size_t)i].bedGraph = bedGraph_files[i];
-    fps[(size_t)i].penalty_str = penalty_strs[i];
-    fps[(size_t)i].db = db_files[i];
-  }
-  int first = solve_files(n_problems, fps.data());
-  if (status_out)
-    for (int i = 0; i < n_problems; i++) status_out[i] = fps[(size_t)i].status;
-  return first;
-}
+/* ---- file-level solver (the reference's boundary), directory-level batch with the cache
+ *      protocol, resident penalty search ----------------------------------------------------- */
+#include "peakseg_files.h"
 
 extern "C" char *PeakSegFPOP_status_message(int status, const char *bedGraph, const char *penalty,
                                             const char *db, char *buf, size_t buf_len) {

@@ -74,6 +74,17 @@ class ProblemSet:
     def hbm_bytes(self):
         return int(self._lib.peakseg_hip_problem_set_bytes(self._h))
 
+    @property
+    def arena_bytes_used(self):
+        """bytes of the arena the last solve() handed out"""
+        return int(self._lib.peakseg_hip_problem_set_arena_bytes_used(self._h))
+
+    def set_penalty(self, p, penalty):
+        """Change one problem's penalty in place; the next solve() reuses contig and arena."""
+        if self._lib.peakseg_hip_problem_set_set_penalty(self._h, p, float(penalty)) != 0:
+            raise RuntimeError("set_penalty(%d) failed" % p)
+        self.problems[p] = (self.problems[p][0], float(penalty))
+
     def close(self):
         if self._h:
             self._lib.peakseg_hip_problem_set_destroy(self._h)

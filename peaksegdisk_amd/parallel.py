@@ -95,7 +95,7 @@ def predicted_cost(n_bins, penalty_rank, n_penalties):
     return float(n_bins) * (1.0 + penalty_rank / max(1.0, n_penalties - 1.0))
 
 
-def solve_grid(contigs, penalties, dist=None, device=0, lib=None):
+def solve_grid(contigs, penalties, dist=None, device=0, lib=None, stats=None):
     """Solve every (contig, penalty) problem of a grid across the ranks of `dist`
     (BASELINE.json configs[3]: 24 contigs x 64 penalties over 8 GPUs).
 
@@ -104,7 +104,8 @@ def solve_grid(contigs, penalties, dist=None, device=0, lib=None):
     needs, solves its shard in one problem set, and rank 0 receives everything through one
     gather.  Returns on rank 0 a dict (contig_index, penalty_index) -> dict(seg_start,
     seg_mean, summary) where summary = [n_segments, n_equality, max_intervals,
-    total_intervals, best_cost]; None on other ranks."""
+    total_intervals, best_cost]; None on other ranks.  stats (a dict, optional) receives this
+    rank's forward_ms (HIP events), kernel_build and hbm_bytes."""
     from .grid import ProblemSet
     world = 1 if dist is None else dist.get_world_size()
     rank = 0 if dist is None else dist.get_rank()
@@ -120,7 +121,10 @@ def solve_grid(contigs, penalties, dist=None, device=0, lib=None):
         pset = ProblemSet([contigs[c] for c in used],
                           [(local_of[problems[i][0]], penalties[problems[i][1]]) for i in mine],
                           device=device or 0, lib=lib)
-        pset.solve()
+        f_ms, _ = pset.solve()
+        if stats is not None:
+            stats.update(forward_ms=f_ms, kernel_build=pset.kernel_build,
+                         hbm_bytes=pset.hbm_bytes, problems=len(mine))
         for k in range(len(mine)):
             r = pset.result(k)
             start, mean = pset.segments(k)
