@@ -74,6 +74,32 @@ def cpu_model_name():
     return "unknown"
 
 
+def host_cores():
+    """Cores this process may actually use: the affinity mask, cut by the cgroup CPU quota
+    (a GPU box hands each GPU's container a share of a large host)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    cores = min(cores, max(1, int(round(int(parts[0]) / int(parts[1])))))
+            else:
+                quota = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read())
+                if quota > 0:
+                    cores = min(cores, max(1, int(round(quota / period))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return cores
+
+
 def cpu_baseline(chrom_start, chrom_end, count, penalties, bins_one, bins_all):
     """Time oracle_cli_libm -- one process per (contig, penalty), cost-function database on
     local scratch, as the reference runs -- on a bounded sample of the bench workload: the
@@ -86,10 +112,7 @@ def cpu_baseline(chrom_start, chrom_end, count, penalties, bins_one, bins_all):
     cli = os.path.join(ROOT, "oracle", "_build", "oracle_cli_libm")
     if not os.path.exists(cli):
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = host_cores()
     work = tempfile.mkdtemp(prefix="psd_cpu_")
 
     def run_one(bg, pen, k):

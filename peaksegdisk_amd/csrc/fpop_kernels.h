@@ -97,7 +97,7 @@ PSD_D bool arena_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &f, i
                             unsigned long long fn_index) {
   const int lane = lane_id();
   if (n > cur.room - cur.used) {
-    unsigned long long base = psd_d2u(uniform_d(psd_u2d(arena_take(a, n))));
+    unsigned long long base = psd_d2u(uniform_d(psd_u2d(arena_take(*a.self, n))));
     if (base == ~0ull) return false;
     cur.base = base;
     cur.used = 0;
@@ -128,7 +128,7 @@ PSD_D bool scale_add_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &
   const int lane = lane_id();
   bool ok = true;
   if (store && n > cur.room - cur.used) {
-    unsigned long long base = psd_d2u(uniform_d(psd_u2d(arena_take(a, n))));
+    unsigned long long base = psd_d2u(uniform_d(psd_u2d(arena_take(*a.self, n))));
     if (base == ~0ull) {
       ok = false;
       store = false;
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
     const int n_other = uniform_i(g_sm.n[id_other_prev]);
     /* come back from HBM when both functions fit comfortably again */
     if (in_hbm && n_own <= LDS_CAP / 2 && n_other <= LDS_CAP / 2) {
-      move_list_hbm(a, spill_slot, id_own_prev, n_own, 0);
+      move_list_hbm(*a.self, spill_slot, id_own_prev, n_own, 0);
       in_hbm = false;
       block_sync(chain);
     }
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
     for (;;) { /* at most two passes: LDS, then HBM after an overflow */
       if (t == 0) {
         ArenaCursor cur0 = cur; /* only this copy has its address taken */
-        n_new = uniform_i(first_point(a, cur0, fn0, chain, contig, coverage, id_own_new));
+        n_new = uniform_i(first_point(*a.self, cur0, fn0, chain, contig, coverage, id_own_new));
         cur = cur0;
       } else if (!in_hbm) {
 #ifdef PSD_CALL_LDS_OPS /* throughput build: operations out of line (register budget) */
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
         if (n_new == -WERR_SERIAL) { /* not the usual case, or it needs the sequential replay */
           ArenaCursor cur_gen = cur; /* only this copy has its address taken */
           n_new = uniform_i(chain_step_lds<USE_HELPER>(
-              a, cur_gen, fn0 + (unsigned long long)t, chain, t, id_other_prev, n_other,
+              *a.self, cur_gen, fn0 + (unsigned long long)t, chain, t, id_other_prev, n_other,
               id_own_prev, n_own, id_own_new, penalty / cum_weight_prev_i, cum_weight_prev_i, w,
               coverage, cum_weight_new));
           cur = cur_gen;
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
 #endif
       } else {
         ArenaCursor cur_hbm = cur; /* only this copy has its address taken */
-        n_new = uniform_i(chain_step_hbm(a, cur_hbm, fn0 + (unsigned long long)t, spill_slot, chain, t,
+        n_new = uniform_i(chain_step_hbm(*a.self, cur_hbm, fn0 + (unsigned long long)t, spill_slot, chain, t,
                                id_other_prev, n_other, id_own_prev, n_own, id_own_new,
                                penalty / cum_weight_prev_i, cum_weight_prev_i, w, coverage,
                                cum_weight_new));
@@ -642,13 +642,13 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
       if (status == PST_LDS_OVERFLOW && !in_hbm && a.spill_cap > LDS_CAP && t > 0) {
         /* redo this data point with the lists in HBM: every wave moves its own t-1 list */
         if (spill_slot < 0) {
-          spill_slot = take_spill_slot(a, chain);
+          spill_slot = take_spill_slot(*a.self, chain);
           if (spill_slot < 0) {
             status = PST_SPILL_FULL;
             break;
           }
         }
-        move_list_hbm(a, spill_slot, id_own_prev, n_own, 1);
+        move_list_hbm(*a.self, spill_slot, id_own_prev, n_own, 1);
         in_hbm = true;
         status = 0;
         block_sync(chain);

@@ -22,7 +22,17 @@
 namespace psd {
 namespace PSD_VARIANT {
 
-constexpr double NEWTON_EPSILON = 1e-12; /* fpl:9 */
+constexpr double NEWTON_EPSILON_VALUE = 1e-12; /* fpl:9 */
+/* The tolerance is compared against in some sixty places of a step.  As a literal every use
+ * costs two scalar moves (an fp64 literal cannot be an operand).  Keeping it in a vector
+ * register pair like the exp/log constants (-DPSD_EPS_IN_VGPR) measured 0.5% slower
+ * (profiles/r02/ab_uniform_args.log): the pair adds to a register file that already spills. */
+#undef NEWTON_EPSILON
+#if defined(PSD_MATH_VK) && defined(__HIP_DEVICE_COMPILE__) && defined(PSD_EPS_IN_VGPR)
+#define NEWTON_EPSILON (psd_vk(NEWTON_EPSILON_VALUE))
+#else
+#define NEWTON_EPSILON NEWTON_EPSILON_VALUE
+#endif
 #ifdef PSD_NEWTON_STEPS /* tests only: force the step-cap fallback of the root finders */
 constexpr int NEWTON_STEPS = PSD_NEWTON_STEPS;
 #else
@@ -119,8 +129,8 @@ PSD_D bool has_two_roots(const Coef &c, const PieceOpt &o, double equals) {
  * with the bracket -- same iterates, same result. */
 
 /* fpl:69-127 in full: Newton in mean space from argmin_mean+1, with the bracket fallback. */
-PSD_COLD_DEV double larger_root_full(const Coef &c, double optimal_mean, double optimal_cost,
-                                          double equals) {
+PSD_COLD_DEV double larger_root_full(Coef c, double optimal_mean, double optimal_cost,
+                                     double equals) {
   double candidate_root = optimal_mean + 1;
   double candidate_cost, deriv;
   double closest_positive_cost = PSD_INF, closest_positive_mean = PSD_INF;
@@ -182,8 +192,8 @@ PSD_D double get_larger_root(const Coef &c, const PieceOpt &o, double max_log_me
 }
 
 /* fpl:129-190 in full: Newton in log-mean space from argmin-1, with the bracket fallback. */
-PSD_COLD_DEV double smaller_root_full(const Coef &c, double optimal_log_mean,
-                                           double optimal_cost, double equals) {
+PSD_COLD_DEV double smaller_root_full(Coef c, double optimal_log_mean, double optimal_cost,
+                                      double equals) {
   double candidate_root = optimal_log_mean - 1;
   double candidate_cost, deriv;
   double closest_positive_cost = PSD_INF, closest_positive_log_mean = PSD_INF;

@@ -45,6 +45,11 @@ struct ProbResult {
 };
 
 struct DeviceArgs {
+  /* Device address of a copy of this block.  The kernel receives the block by value (scalar
+   * loads from the kernel-argument segment); out-of-line device functions get *self instead of
+   * a reference to the by-value copy, which the compiler would have to spill to scratch memory
+   * -- and then read back from there in the kernel's loop as well. */
+  const DeviceArgs *self;
   int n_problems;
   /* per problem */
   const int *prob_contig;

@@ -550,6 +550,7 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
       (st = dev_alloc(s, &d.result, (size_t)n_problems)) ||
       (st = dev_alloc(s, &d.ar_next_chunk, (size_t)1)) ||
       (st = dev_alloc(s, &d.spill_next, (size_t)1)) ||
+      (st = dev_alloc(s, const_cast<psd::DeviceArgs **>(&d.self), (size_t)1)) ||
       (st = dev_alloc(s, &d.fn_ref, (size_t)fn_off)) ||
       (st = dev_alloc(s, &d.seg_start, (size_t)seg_off)) ||
       (st = dev_alloc(s, &d.seg_mean, (size_t)seg_off))) {
@@ -641,6 +642,8 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
   for (int attempt = 0;; attempt++) {
     HIP_TRY(hipMemsetAsync(s->d.ar_next_chunk, 0, sizeof(unsigned long long), s->stream));
     HIP_TRY(hipMemsetAsync(s->d.spill_next, 0, sizeof(int), s->stream));
+    HIP_TRY(hipMemcpyAsync(const_cast<psd::DeviceArgs *>(s->d.self), &s->d, sizeof(psd::DeviceArgs),
+                           hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipEventRecord(s->ev[0], s->stream));
     if (s->throughput)
       hipLaunchKernelGGL(psd::thr::fpop_forward_kernel, dim3((unsigned)s->n_problems),
@@ -669,7 +672,7 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
       spill_full = spill_full || r.status == psd::PST_SPILL_FULL;
     }
     if (!arena_full && !spill_full) break;
-    if (attempt >= 6) {
+    if (attempt >= 8) {
       set_error("cost-function arena (%llu pieces) / spill pool (%d slots) still too small after "
                 "%d reruns", s->arena_pieces, s->spill_slots, attempt);
       return ERROR_DEVICE_MEMORY;
@@ -690,8 +693,22 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
         set_error("cost-function arena of %llu pieces is too small", s->arena_pieces);
         return ERROR_DEVICE_MEMORY;
       }
-      /* grow and rerun the whole set */
+      /* grow and rerun the whole set: at least twice the size, and what the problems' progress
+       * says the whole set needs (pieces handed out so far / share of the data points done) */
       unsigned long long bigger = s->arena_pieces * 2ull;
+      {
+        double done = 0.0, all = 0.0;
+        for (int p = 0; p < s->n_problems; p++) {
+          const double n = (double)s->contig_n[(size_t)s->prob_contig[(size_t)p]];
+          const psd::ProbResult &r = s->results[(size_t)p];
+          all += n;
+          done += r.status == 0 ? n : (double)r.step_reached;
+        }
+        if (done > 0.0) {
+          double need = (double)s->arena_pieces * (all / done) * 1.3;
+          if (need > (double)bigger) bigger = (unsigned long long)need;
+        }
+      }
       unsigned long long old_pieces = s->arena_pieces;
       free_arena(s);
       unsigned long long fit = arena_fit(s);

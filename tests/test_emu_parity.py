@@ -12,6 +12,7 @@ import subprocess
 import pytest
 
 import test_gpu_parity as gp
+import test_gpu_round2 as gp2
 from conftest import ROOT
 
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
@@ -175,3 +176,15 @@ def test_emu_grid_properties_small(psd):
 
 def test_emu_fuzz_tiny_problems(psd, oracle_det, tmp_path):
     gp.test_fuzz_tiny_problems(psd, oracle_det, tmp_path, 150, 6)
+
+
+def test_emu_resident_search_exact_sequence(psd, oracle_det, known_answers, tmp_path):
+    gp2.test_resident_search_exact_sequence(psd, oracle_det, known_answers, tmp_path)
+
+
+def test_emu_dir_batch_cache_and_timing(psd, oracle_det, tmp_path):
+    gp2.test_dir_batch_cache_and_timing(psd, oracle_det, tmp_path, 500)
+
+
+def test_emu_spill_pool_and_arena_regrowth(psd, oracle_det, tmp_path, monkeypatch):
+    gp2.test_spill_pool_and_arena_regrowth(psd, oracle_det, tmp_path, monkeypatch, 700)
