@@ -57,7 +57,7 @@ def parse_args(argv=None):
                     help="grid mode: contig lengths are log-uniform in [1e5, 1e7] x this")
     ap.add_argument("--cpu-bins", type=int, default=40000,
                     help="CPU baseline, one core: first this many bins x every penalty")
-    ap.add_argument("--cpu-bins-all", type=int, default=200000,
+    ap.add_argument("--cpu-bins-all", type=int, default=1000000,
                     help="CPU baseline, all cores: first this many bins x every penalty")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args(argv)
@@ -102,11 +102,17 @@ def host_cores():
 
 def cpu_baseline(chrom_start, chrom_end, count, penalties, bins_one, bins_all):
     """Time oracle_cli_libm -- one process per (contig, penalty), cost-function database on
-    local scratch, as the reference runs -- on a bounded sample of the bench workload: the
-    first bins of the contig at EVERY penalty of the grid, (i) one process at a time on one
-    core and (ii) a pool with one worker per host core.  kind = "port": the reference's own
-    solver sources include R.h, which this image lacks, so they cannot be built here
-    (DESIGN.md section 2); the oracle is the C restatement pinned by the reference's fixtures."""
+    local scratch, as the reference runs -- on the bench workload:
+      (i)  one process at a time on one core: the first `bins_one` bins of the contig at EVERY
+           penalty of the grid (a bounded sample: the CPU needs ~10 min for the whole grid);
+      (ii) a pool with one worker per usable host core: the first `bins_all` bins (default:
+           the whole contig) at every penalty.  Besides the all-cores rate this gives the CPU
+           seconds (user + system, from wait4) of every process, i.e. what one core needs for
+           the grid at the bench's own contig length -- per-bin cost grows with the length, so
+           the short sample of (i) flatters the CPU.
+    kind = "port": the reference's own solver sources include R.h, which this image lacks, so
+    they cannot be built here; the oracle is the C restatement pinned by
+    the reference's fixtures."""
     from concurrent.futures import ThreadPoolExecutor
     from peaksegdisk_amd import synthetic
     cli = os.path.join(ROOT, "oracle", "_build", "oracle_cli_libm")
@@ -116,10 +122,14 @@ def cpu_baseline(chrom_start, chrom_end, count, penalties, bins_one, bins_all):
     work = tempfile.mkdtemp(prefix="psd_cpu_")
 
     def run_one(bg, pen, k):
-        st = subprocess.run([cli, bg, pen, os.path.join(work, "db%d" % k)],
-                            stdout=subprocess.DEVNULL).returncode
-        if st != 0:
-            raise RuntimeError("oracle_cli_libm status %d" % st)
+        """returns the child's user + system CPU seconds"""
+        proc = subprocess.Popen([cli, bg, pen, os.path.join(work, "db%d" % k)],
+                                stdout=subprocess.DEVNULL)
+        _, status, ru = os.wait4(proc.pid, 0)
+        proc.returncode = os.waitstatus_to_exitcode(status)
+        if proc.returncode != 0:
+            raise RuntimeError("oracle_cli_libm status %d" % proc.returncode)
+        return ru.ru_utime + ru.ru_stime
 
     try:
         n1 = min(bins_one, len(count))
@@ -136,7 +146,8 @@ def cpu_baseline(chrom_start, chrom_end, count, penalties, bins_one, bins_all):
         synthetic.write_bedgraph(bg2, chrom_start[:n2], chrom_end[:n2], count[:n2])
         t0 = time.time()
         with ThreadPoolExecutor(max_workers=cores) as pool:  # each task is one child process
-            list(pool.map(lambda kp: run_one(bg2, kp[1], 1000 + kp[0]), enumerate(penalties)))
+            cpu_s = list(pool.map(lambda kp: run_one(bg2, kp[1], 1000 + kp[0]),
+                                  enumerate(penalties)))
         wall2 = time.time() - t0
     finally:
         shutil.rmtree(work, ignore_errors=True)
@@ -144,11 +155,16 @@ def cpu_baseline(chrom_start, chrom_end, count, penalties, bins_one, bins_all):
         "value": n1 * len(penalties) / wall1, "unit": "bins/s", "cores": 1, "kind": "port",
         "sample": "first %d bins of the contig x all %d penalties, oracle_cli_libm (C "
                   "restatement, glibc exp/log, disk-backed store), one process per problem, "
-                  "one at a time, %.1f s" % (n1, len(penalties), wall1),
+                  "one at a time, %.1f s wall" % (n1, len(penalties), wall1),
         "all_cores": {
             "value": n2 * len(penalties) / wall2, "unit": "bins/s", "cores": cores,
-            "sample": "first %d bins x all %d penalties, pool of %d processes, %.1f s"
+            "sample": "first %d bins x all %d penalties, pool of %d processes, %.1f s wall"
                       % (n2, len(penalties), cores, wall2),
+        },
+        "one_core_at_length": {
+            "value": n2 * len(penalties) / sum(cpu_s), "unit": "bins/s", "cores": 1,
+            "sample": "the same %d processes: %d bins x %d penalties / their summed user+system "
+                      "CPU time (%.1f s)" % (len(penalties), n2, len(penalties), sum(cpu_s)),
         },
         "cpu_model": cpu_model_name(),
         "why_port": "the reference's solver sources include R.h (absent here): unbuildable, "
@@ -383,6 +399,8 @@ def main():
                                                args.cpu_bins_all)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             out["gpu_over_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["all_cores"]["value"]
+            out["gpu_over_cpu_core_at_length"] = \
+                out["value"] / out["cpu_baseline"]["one_core_at_length"]["value"]
         print(json.dumps(out))
     if args.mode == "weak":
         pset.close()

@@ -43,6 +43,7 @@ extern "C" {
  *                               the arena is doubled and the set rerun when it proves too small)
  * PEAKSEG_HIP_SPILL_CAP / _SPILL_SLOTS  capacity (pieces per list, at most 32767) and initial
  *                               number of slots of the HBM spill pool for functions that outgrow LDS
+ * PEAKSEG_HIP_CHECKPOINT=K / PEAKSEG_HIP_NO_CHECKPOINT=1  force / forbid the checkpointed store
  * PEAKSEG_HIP_VARIANT=lat|thr   force a build of the forward kernel
  * PEAKSEG_HIP_TIMING=1          phase timings of the file-level calls on stderr */
 
@@ -164,6 +165,12 @@ const char *peakseg_hip_problem_set_kernel_build(psd_problem_set *set);
 
 /* bytes of HBM held by the set (arena + tables) */
 unsigned long long peakseg_hip_problem_set_bytes(psd_problem_set *set);
+
+/* 0 when every cost function is kept in HBM (the reference's store, in memory), K > 0 when the
+ * set uses the checkpointed store: only a checkpoint every K data points is kept and the
+ * decoding recomputes the blocks it walks through (chosen automatically when the full store
+ * would not fit; PEAKSEG_HIP_CHECKPOINT=K forces it, PEAKSEG_HIP_NO_CHECKPOINT=1 forbids it). */
+int peakseg_hip_problem_set_checkpoint_interval(psd_problem_set *set);
 
 /* bytes of the arena the last solve handed out (whole chunks) */
 unsigned long long peakseg_hip_problem_set_arena_bytes_used(psd_problem_set *set);

@@ -110,6 +110,8 @@ def declare(lib):
     lib.peakseg_hip_problem_set_set_penalty.restype = c.c_int
     lib.peakseg_hip_problem_set_arena_bytes_used.argtypes = [c.c_void_p]
     lib.peakseg_hip_problem_set_arena_bytes_used.restype = c.c_ulonglong
+    lib.peakseg_hip_problem_set_checkpoint_interval.argtypes = [c.c_void_p]
+    lib.peakseg_hip_problem_set_checkpoint_interval.restype = c.c_int
     lib.peakseg_hip_paste_double.argtypes = [c.c_double, c.c_char_p, c.c_size_t]
     lib.peakseg_hip_paste_double.restype = c.c_int
     return lib
@@ -125,7 +127,7 @@ EXPORTED_SYMBOLS = [
     "peakseg_hip_problem_set_profile", "peakseg_hip_problem_set_kernel_build",
     "PeakSegFPOP_dir_batch", "PeakSegFPOP_sequential_search",
     "peakseg_hip_problem_set_set_penalty", "peakseg_hip_problem_set_arena_bytes_used",
-    "peakseg_hip_paste_double",
+    "peakseg_hip_paste_double", "peakseg_hip_problem_set_checkpoint_interval",
 ]
 
 if not os.path.exists(LIB_PATH):

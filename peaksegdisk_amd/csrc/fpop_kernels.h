@@ -72,12 +72,14 @@ PSD_D void copy_list_wave(const L &src, int n, const L &dst) {
 struct ArenaCursor {
   unsigned long long base; /* first piece of the current chunk run */
   int used, room;
+  int store; /* 0: the forward pass of the checkpointed store keeps no per-step records */
 };
 
 /* Reserve arena room for a function of n pieces: the next run of whole chunks for this wave
  * (cold: once per chunk of 2^ar_chunk_log2 pieces).  Returns the first piece index of the run;
  * ~0 when the arena is exhausted. */
 PSD_COLD_DEV unsigned long long arena_take(const DeviceArgs &a, int n) {
+  if (a.ckpt_interval > 0) return ~0ull; /* checkpointed store: the wave's region is all it has */
   const int lg = a.ar_chunk_log2;
   const unsigned long long chunks = ((unsigned long long)uniform_i(n) + (1ull << lg) - 1ull) >> lg;
   unsigned long long first = 0;
@@ -96,6 +98,7 @@ template <class L>
 PSD_D bool arena_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &f, int n,
                             unsigned long long fn_index) {
   const int lane = lane_id();
+  if (!cur.store) return true;
   if (n > cur.room - cur.used) {
     unsigned long long base = psd_d2u(uniform_d(psd_u2d(arena_take(*a.self, n))));
     if (base == ~0ull) return false;
@@ -127,6 +130,7 @@ PSD_D bool scale_add_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &
                                 double add_linear, double add_log, double inv_cum_weight) {
   const int lane = lane_id();
   bool ok = true;
+  store = store && cur.store != 0;
   if (store && n > cur.room - cur.used) {
     unsigned long long base = psd_d2u(uniform_d(psd_u2d(arena_take(*a.self, n))));
     if (base == ~0ull) {
@@ -388,26 +392,35 @@ PSD_COLD_DEV int chain_step_hbm(const DeviceArgs &a, ArenaCursor &cur,
  * every function has at most LDS_CAP pieces; when an operation overflows, the step is redone
  * with all lists in the HBM spill area, and the problem returns to LDS once both functions
  * have shrunk below LDS_CAP/2. */
+/* State of the decoding (drv:399-442) between two calls of backtrack_wave. */
+struct BtState {
+  double best_log_mean, prev_log_mean;
+  int prev_seg_end, prev_seg_offset; /* offset 0: the next function is an up one, N: a down one */
+  int n_seg, n_eq, status;
+};
+
 /* Decode the optimal segmentation (drv:399-442): one wave, right after the forward pass of
  * its problem (the arena records it follows were written by this workgroup; fast problems
- * decode while slower ones are still in their forward pass). */
-PSD_D void backtrack_wave(const DeviceArgs &a, int p, ProbResult &r) {
+ * decode while slower ones are still in their forward pass).  Follows the chain of segment
+ * ends while it stays at data points >= t_lo (0: to the end); the record of function
+ * (up/down, t) is fn_ref[fn_up/fn_down + t - t_origin].  Returns with bt.prev_seg_end < t_lo. */
+PSD_D void backtrack_wave(const DeviceArgs &a, int p, int N, BtState &bt, unsigned long long fn_up,
+                          unsigned long long fn_down, int t_origin, int t_lo) {
   const int lane = lane_id();
-  const int N = a.contig_n[a.prob_contig[p]];
-  const unsigned long long fn0 = (unsigned long long)a.prob_fn_off[p];
   int *seg_start = a.seg_start + a.prob_seg_off[p];
   double *seg_mean = a.seg_mean + a.prob_seg_off[p];
-  double best_log_mean = r.best_log_mean;
-  double prev_log_mean = r.prev_log_mean;
-  int prev_seg_end = r.prev_seg_end;
-  int prev_seg_offset = 0;
-  int n_seg = 0, n_eq = 0, status = 0;
-  while (0 <= prev_seg_end) {
+  double best_log_mean = bt.best_log_mean;
+  double prev_log_mean = bt.prev_log_mean;
+  int prev_seg_end = bt.prev_seg_end;
+  int prev_seg_offset = bt.prev_seg_offset;
+  int n_seg = bt.n_seg, n_eq = bt.n_eq, status = bt.status;
+  while (t_lo <= prev_seg_end && status == 0) {
     if (n_seg >= N) { /* more segments than data points: cannot happen for a valid store */
       status = PST_BACKTRACK;
       break;
     }
-    unsigned long long ref = a.fn_ref[fn0 + (unsigned long long)(prev_seg_offset + prev_seg_end)];
+    unsigned long long ref = a.fn_ref[(prev_seg_offset ? fn_down : fn_up) +
+                                      (unsigned long long)(prev_seg_end - t_origin)];
     unsigned long long off = ref >> FN_COUNT_BITS;
     int n = (int)(ref & ((1ull << FN_COUNT_BITS) - 1));
     if (lane == 0) {
@@ -450,16 +463,20 @@ PSD_D void backtrack_wave(const DeviceArgs &a, int p, ProbResult &r) {
       break;
     }
   }
-  if (status == 0) {
+  if (status == 0 && prev_seg_end < 0) { /* the first segment (drv:442) */
     if (lane == 0) {
       seg_start[n_seg] = -1;
       seg_mean[n_seg] = d_exp(best_log_mean);
     }
     n_seg++;
   }
-  r.n_segments = n_seg;
-  r.n_equality = n_eq;
-  r.status = status;
+  bt.best_log_mean = best_log_mean;
+  bt.prev_log_mean = prev_log_mean;
+  bt.prev_seg_end = prev_seg_end;
+  bt.prev_seg_offset = prev_seg_offset;
+  bt.n_seg = n_seg;
+  bt.n_eq = n_eq;
+  bt.status = status;
 }
 
 #ifdef PSD_HELPER_WAVES
@@ -492,6 +509,54 @@ PSD_COLD_DEV int take_spill_slot(const DeviceArgs &a, int chain) {
 }
 
 
+/* ---- checkpointed store ----------------------------------------
+ * Checkpoint slot k of a problem holds the two live functions after data point (k+1) K: per
+ * slot 2 + 12 cap doubles {cum_weight, -, then per chain Lin, Log, Con, mn, mx, prv} and
+ * 2 + 2 cap ints {n_up, n_down, then per chain data_i}. */
+PSD_D GlobalList ckpt_list(const DeviceArgs &a, long long slot, int chain) {
+  const size_t cap = (size_t)a.ckpt_cap;
+  double *f = a.ckpt_f64 + (size_t)slot * (2 + 12 * cap) + 2 + (size_t)chain * 6 * cap;
+  GlobalList r;
+  r.Lin_ = f;
+  r.Log_ = f + cap;
+  r.Con_ = f + 2 * cap;
+  r.mn_ = f + 3 * cap;
+  r.mx_ = f + 4 * cap;
+  r.prv_ = f + 5 * cap;
+  r.di_ = a.ckpt_i32 + (size_t)slot * (2 + 2 * cap) + 2 + (size_t)chain * cap;
+  return r;
+}
+/* this chain's function (LDS list `id`, n pieces) and the cumulated weight -> slot k */
+PSD_COLD_DEV void ckpt_save(const DeviceArgs &a, int p, int k, int chain, int id, int n,
+                            double cum_weight) {
+  p = uniform_i(p);
+  k = uniform_i(k);
+  chain = uniform_i(chain);
+  n = uniform_i(n);
+  const long long slot = a.prob_ckpt_off[p] + k;
+  copy_list_across(lds_list(uniform_i(id)), n, ckpt_list(a, slot, chain));
+  if (lane_id() == 0) {
+    const size_t cap = (size_t)a.ckpt_cap;
+    a.ckpt_i32[(size_t)slot * (2 + 2 * cap) + (size_t)chain] = n;
+    if (chain == 0) a.ckpt_f64[(size_t)slot * (2 + 12 * cap)] = uniform_d(cum_weight);
+  }
+}
+/* slot k -> LDS list `id`; returns the piece count */
+PSD_COLD_DEV int ckpt_load(const DeviceArgs &a, int p, int k, int chain, int id) {
+  p = uniform_i(p);
+  k = uniform_i(k);
+  chain = uniform_i(chain);
+  const long long slot = a.prob_ckpt_off[p] + k;
+  const size_t cap = (size_t)a.ckpt_cap;
+  const int n = uniform_i(a.ckpt_i32[(size_t)slot * (2 + 2 * cap) + (size_t)chain]);
+  copy_list_across(ckpt_list(a, slot, chain), n, lds_list(uniform_i(id)));
+  return n;
+}
+PSD_COLD_DEV double ckpt_cum_weight(const DeviceArgs &a, int p, int k) {
+  const long long slot = a.prob_ckpt_off[uniform_i(p)] + uniform_i(k);
+  return a.ckpt_f64[(size_t)slot * (2 + 12 * (size_t)a.ckpt_cap)];
+}
+
 /* PSD_KERNEL_WAVES_PER_EU (throughput build): keep the kernel's own register use within the
  * budget of that many waves per SIMD, as the out-of-line operations already are */
 #undef PSD_KERNEL_OCC
@@ -511,8 +576,6 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
   const double penalty = a.prob_penalty[p];
   const int *count = a.count + a.contig_off[contig];
   const int *weight = a.weight + a.contig_off[contig];
-  const unsigned long long fn0 =
-      (unsigned long long)a.prob_fn_off[p] + (chain == 1 ? (unsigned long long)N : 0ull);
   const LdsList mlist = lds_list(4 + chain);
   LdsScratch lsc;
   lsc.w = chain;
@@ -543,10 +606,21 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
   }
 #endif
 
+  /* Passes over the data.  Full store (ckpt_interval = 0): one pass, every function recorded,
+   * then the decoding.  Checkpointed store: a forward pass that records nothing but a
+   * checkpoint every K data points, then, led by the decoding, one pass per block of K data
+   * points that holds a segment end, from that block's checkpoint and with the records kept
+   * in this wave's region of the arena. */
+  const int K = a.ckpt_interval;
+  const unsigned long long fn_stride = K > 0 ? (unsigned long long)K + 1ull : (unsigned long long)N;
+  const unsigned long long fn_up = (unsigned long long)a.prob_fn_off[p];
+  const unsigned long long fn_down = fn_up + fn_stride;
+  const unsigned long long fn_mine = chain == 1 ? fn_down : fn_up;
   ArenaCursor cur;
   cur.base = 0;
   cur.used = 0;
   cur.room = 0;
+  cur.store = K > 0 ? 0 : 1;
   unsigned long long total_intervals = 0;
   int max_intervals = 0;
   int spill_steps = 0;
@@ -557,14 +631,30 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
   bool in_hbm = false; /* where the lists of step t-1 live */
   int spill_slot = -1; /* this problem's slot of the HBM spill pool, taken on first overflow */
   int t = 0;
+  int t_lo = 0, t_hi = N; /* data points of this pass */
+  int t_origin = 0;       /* fn_ref index of data point t: t - t_origin */
+  int next_ckpt = K > 0 ? K : -1;
+  bool forward = true;    /* the first pass */
+  int step_reached = 0;
+  BtState bt;
+  bt.best_log_mean = bt.prev_log_mean = 0.0;
+  bt.prev_seg_end = -1;
+  bt.prev_seg_offset = 0;
+  bt.n_seg = bt.n_eq = bt.status = 0;
+  ProbResult r;
+  r.best_cost = 0.0;
+  r.best_log_mean = 0.0;
+  r.prev_log_mean = 0.0;
+  r.prev_seg_end = -1;
   unsigned sync_no = 0; /* parity slot of the abort flags: one per barrier */
 #ifdef PSD_PROFILE
   long long t_begin = cycle_now();
 #endif
-  for (; t < N; t++) {
+  for (;;) { /* passes */
+  for (t = t_lo; t < t_hi; t++) {
     PSD_PROF_T0();
-    if ((t & 63) == 0) { /* coalesced read of the next 64 data points */
-      int tt = t + lane;
+    if ((t & 63) == 0 || t == t_lo) { /* coalesced read of the next 64 data points */
+      int tt = (t & ~63) + lane;
       cnt_reg = tt < N ? count[tt] : 0;
       wt_reg = tt < N ? weight[tt] : 0;
     }
@@ -576,6 +666,7 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
     const int id_other_prev = 2 * (1 - chain) + b;
     const int n_own = uniform_i(g_sm.n[id_own_prev]);
     const int n_other = uniform_i(g_sm.n[id_other_prev]);
+    const unsigned long long fn_index = fn_mine + (unsigned long long)(t - t_origin);
     /* come back from HBM when both functions fit comfortably again */
     if (in_hbm && n_own <= LDS_CAP / 2 && n_other <= LDS_CAP / 2) {
       move_list_hbm(*a.self, spill_slot, id_own_prev, n_own, 0);
@@ -586,11 +677,11 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
     for (;;) { /* at most two passes: LDS, then HBM after an overflow */
       if (t == 0) {
         ArenaCursor cur0 = cur; /* only this copy has its address taken */
-        n_new = uniform_i(first_point(*a.self, cur0, fn0, chain, contig, coverage, id_own_new));
+        n_new = uniform_i(first_point(*a.self, cur0, fn_index, chain, contig, coverage, id_own_new));
         cur = cur0;
       } else if (!in_hbm) {
 #ifdef PSD_CALL_LDS_OPS /* throughput build: operations out of line (register budget) */
-        n_new = chain_step<USE_HELPER>(a, cur, fn0 + (unsigned long long)t, chain, t,
+        n_new = chain_step<USE_HELPER>(a, cur, fn_index, chain, t,
                            lds_list(id_other_prev), n_other, lds_list(id_own_prev),
                            n_own, lds_list(id_own_new), mlist, lsc, LDS_CAP,
                            penalty / cum_weight_prev_i, cum_weight_prev_i, w, coverage,
@@ -599,14 +690,14 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
         n_new = -WERR_SERIAL;
         if (t >= 2 && n_other <= FAST_MAX_OTHER && n_own <= FAST_MAX_OWN) {
           n_new = chain_step_fast<USE_HELPER>(
-              a, cur, fn0 + (unsigned long long)t, chain, t, lds_list(id_other_prev), n_other,
+              a, cur, fn_index, chain, t, lds_list(id_other_prev), n_other,
               lds_list(id_own_prev), n_own, lds_list(id_own_new), mlist, lsc,
               penalty / cum_weight_prev_i, cum_weight_prev_i, w, coverage, cum_weight_new);
         }
         if (n_new == -WERR_SERIAL) { /* not the usual case, or it needs the sequential replay */
           ArenaCursor cur_gen = cur; /* only this copy has its address taken */
           n_new = uniform_i(chain_step_lds<USE_HELPER>(
-              *a.self, cur_gen, fn0 + (unsigned long long)t, chain, t, id_other_prev, n_other,
+              *a.self, cur_gen, fn_index, chain, t, id_other_prev, n_other,
               id_own_prev, n_own, id_own_new, penalty / cum_weight_prev_i, cum_weight_prev_i, w,
               coverage, cum_weight_new));
           cur = cur_gen;
@@ -614,7 +705,7 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
 #endif
       } else {
         ArenaCursor cur_hbm = cur; /* only this copy has its address taken */
-        n_new = uniform_i(chain_step_hbm(*a.self, cur_hbm, fn0 + (unsigned long long)t, spill_slot, chain, t,
+        n_new = uniform_i(chain_step_hbm(*a.self, cur_hbm, fn_index, spill_slot, chain, t,
                                id_other_prev, n_other, id_own_prev, n_own, id_own_new,
                                penalty / cum_weight_prev_i, cum_weight_prev_i, w, coverage,
                                cum_weight_new));
@@ -642,7 +733,7 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
       if (status == PST_LDS_OVERFLOW && !in_hbm && a.spill_cap > LDS_CAP && t > 0) {
         /* redo this data point with the lists in HBM: every wave moves its own t-1 list */
         if (spill_slot < 0) {
-          spill_slot = take_spill_slot(*a.self, chain);
+          spill_slot = uniform_i(take_spill_slot(*a.self, chain)); /* a call's result: say it is uniform */
           if (spill_slot < 0) {
             status = PST_SPILL_FULL;
             break;
@@ -657,20 +748,91 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
       break;
     }
     if (status != 0) break;
-    total_intervals += (unsigned long long)n_new;
-    if (max_intervals < n_new) max_intervals = n_new;
-    if (in_hbm) spill_steps++;
+    if (forward) {
+      total_intervals += (unsigned long long)n_new;
+      if (max_intervals < n_new) max_intervals = n_new;
+      if (in_hbm) spill_steps++;
+    }
     cum_weight_i = cum_weight_new;
     cum_weight_prev_i = cum_weight_i;
     b = nb;
+    if (t == next_ckpt) { /* checkpointed store, forward pass: keep the two live functions */
+      if (in_hbm) {
+        status = PST_CKPT_SPILL; /* both chains: in_hbm is the same in the two waves */
+        break;
+      }
+      ckpt_save(*a.self, p, t / K - 1, chain, 2 * chain + b, n_new, cum_weight_i);
+      next_ckpt += K;
+    }
   }
-  /* ---- after the last data point: Minimize the final down function (drv:404-406) ---- */
-  if (chain == 0 && lane == 0) {
-    g_sm.total_up = total_intervals;
-    g_sm.max_up = max_intervals;
+  if (forward) step_reached = t;
+  if (status != 0) break;
+  /* ---- after a pass ---- */
+  if (forward) {
+    /* Minimize the final down function (drv:404-406) */
+    if (chain == 0 && lane == 0) {
+      g_sm.total_up = total_intervals;
+      g_sm.max_up = max_intervals;
+    }
   }
   device_fence(); /* the stored functions of both chains are read back by backtrack_wave */
   block_sync(chain);
+  if (chain == 1) {
+    if (forward) {
+      const int id = 2 + b;
+      if (in_hbm) {
+        minimize_wave(global_list(a, spill_slot, id), g_sm.n[id], &r.best_cost, &r.best_log_mean,
+                      &r.prev_seg_end, &r.prev_log_mean);
+      } else {
+        minimize_wave(lds_list(id), g_sm.n[id], &r.best_cost, &r.best_log_mean, &r.prev_seg_end,
+                      &r.prev_log_mean);
+      }
+      bt.best_log_mean = r.best_log_mean;
+      bt.prev_log_mean = r.prev_log_mean;
+      bt.prev_seg_end = r.prev_seg_end;
+    }
+    /* decode as far as the records at hand reach: everything (full store), the segment ends
+     * inside the block just recomputed, or -- after the forward pass of the checkpointed store
+     * -- nothing but the one-segment model's only row */
+    backtrack_wave(a, p, N, bt, fn_up, fn_down, t_origin, (K > 0 && forward) ? N : t_lo);
+  }
+  if (K == 0) break;
+  /* checkpointed store: which block holds the next segment end?  (-1: decoding complete) */
+  if (chain == 1 && lane == 0) {
+    int c = -1;
+    if (bt.status == 0 && bt.prev_seg_end >= 0)
+      c = bt.prev_seg_end == 0 ? 0 : (bt.prev_seg_end - 1) / K;
+    g_sm.bt_next = c;
+  }
+  block_sync(chain);
+  const int c = uniform_i(g_sm.bt_next);
+  if (c < 0) break;
+  /* next pass: data points c K + 1 .. (c + 1) K (block 0 also redoes data point 0), from the
+   * checkpoint after data point c K, records into this wave's region of the arena */
+  forward = false;
+  next_ckpt = -1;
+  t_origin = c * K;
+  t_lo = c == 0 ? 0 : c * K + 1;
+  t_hi = (c + 1) * K + 1 < N ? (c + 1) * K + 1 : N;
+  cur.base = ((unsigned long long)p * 2ull + (unsigned long long)chain) * a.ckpt_region;
+  cur.used = 0;
+  cur.room = (int)a.ckpt_region;
+  cur.store = 1;
+  in_hbm = false;
+  b = 0;
+  if (c == 0) {
+    cum_weight_i = 0.0;
+    cum_weight_prev_i = -1.0;
+    if (lane == 0) g_sm.n[2 * chain] = g_sm.n[2 * chain + 1] = 0;
+  } else {
+    device_fence();
+    const int n_ck = uniform_i(ckpt_load(*a.self, p, c - 1, chain, 2 * chain));
+    if (lane == 0) g_sm.n[2 * chain] = n_ck;
+    cum_weight_i = uniform_d(ckpt_cum_weight(*a.self, p, c - 1));
+    cum_weight_prev_i = cum_weight_i;
+  }
+  block_sync(chain); /* both functions are in LDS before either chain reads the other's */
+  } /* passes */
 #ifdef PSD_HELPER_WAVES
   if (mail_wait(chain)) mail_post(chain, HOP_EXIT);
   else if (lane == 0) g_sm.mail[chain].abort = 1;
@@ -683,31 +845,15 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
   }
 #endif
   if (chain == 1) {
-    ProbResult r;
-    r.best_cost = 0.0;
-    r.best_log_mean = 0.0;
-    r.prev_log_mean = 0.0;
-    r.prev_seg_end = -1;
-    r.status = status;
+    r.status = status != 0 ? status : bt.status;
     r.wave_err = g_sm.abort_err[0] | g_sm.abort_err[1] | g_sm.abort_err[2];
     r.max_intervals = max_intervals > g_sm.max_up ? max_intervals : g_sm.max_up;
     r.total_intervals = total_intervals + g_sm.total_up;
-    r.n_segments = 0;
-    r.n_equality = 0;
+    r.n_segments = bt.n_seg;
+    r.n_equality = bt.n_eq;
     r.n_serial_env = g_sm.serial[0] + g_sm.serial[1];
-    r.step_reached = t;
+    r.step_reached = step_reached;
     r.spill_steps = spill_steps;
-    if (status == 0) {
-      const int id = 2 + b;
-      if (in_hbm) {
-        minimize_wave(global_list(a, spill_slot, id), g_sm.n[id], &r.best_cost, &r.best_log_mean,
-                      &r.prev_seg_end, &r.prev_log_mean);
-      } else {
-        minimize_wave(lds_list(id), g_sm.n[id], &r.best_cost, &r.best_log_mean, &r.prev_seg_end,
-                      &r.prev_log_mean);
-      }
-      backtrack_wave(a, p, r);
-    }
     if (lane == 0) a.result[p] = r;
   }
 }

@@ -26,6 +26,7 @@ enum {
   PST_REF_THROW = 3,     /* the reference would throw / loop / read a list sentinel */
   PST_BACKTRACK = 4,     /* findMean found no piece (the reference would never return) */
   PST_SPILL_FULL = 5,    /* no free slot in the HBM spill pool: host retries with more slots */
+  PST_CKPT_SPILL = 6,    /* checkpointed store: a function to checkpoint has outgrown LDS */
 };
 
 struct ProbResult {
@@ -85,6 +86,18 @@ struct DeviceArgs {
   int spill_cap;
   int spill_slots;
   int *spill_next;
+  /* Checkpointed store (ckpt_interval = 0: every function is stored,
+   * as the reference's DiskVector does).  With ckpt_interval = K > 0 the forward pass keeps no
+   * per-step records, only the two live functions after every K-th data point; the decoding
+   * recomputes, block of K data points by block, the records it walks through, into a private
+   * region of the arena (ckpt_region pieces per chain).  fn_ref then holds 2 (K+1) entries per
+   * problem.  Per checkpoint: 12 ckpt_cap + 2 doubles and 2 ckpt_cap + 2 ints. */
+  int ckpt_interval;
+  int ckpt_cap;
+  unsigned long long ckpt_region;
+  const long long *prob_ckpt_off; /* first checkpoint slot of each problem */
+  double *ckpt_f64;
+  int *ckpt_i32;
 };
 
 }  // namespace psd

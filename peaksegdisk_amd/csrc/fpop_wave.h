@@ -91,6 +91,7 @@ struct SharedBlock {
   int max_up;
   int serial[2];
   int spill_slot; /* slot of the HBM spill pool taken by this problem (take_spill_slot) */
+  int bt_next;    /* checkpointed store: block the decoding needs next, -1 = done */
 #ifdef PSD_HELPER_WAVES
   Mail mail[2];
 #endif
@@ -1362,11 +1363,11 @@ PSD_D void env_classify_lanes(bool valid, const Coef &c1, const Coef &c2, double
   /* phase C: one log site for the degenerate crossing and for argmin() of the difference */
   const double larg = degen ? (-d.Constant / d.Linear) : (-d.Log / d.Linear);
   double lres = 0.0;
-  if (degen_root || rootp) lres = d_log(larg);
   /* phase D: optimum of the difference piece, its end costs, has_two_roots (fpl:1020-1022) */
   PieceOpt o = {0.0, 0.0, 0.0, 0.0};
   double cost_diff_left = 0.0, cost_diff_right = 0.0;
   bool two_roots = false;
+  if (degen_root || rootp) lres = d_log(larg);
   if (rootp) {
     cost_diff_left = get_cost_e(d, a, ea);
     cost_diff_right = get_cost_e(d, b, eb);
@@ -1672,10 +1673,35 @@ PSD_D int min_env_impl(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, i
     const L &own = side ? f2 : f1;
     const L &oth = side ? f1 : f2;
     const bool valid = idx < n_own;
-    double x = 0.0;
+    double x = PSD_INF; /* lanes without an end never count as "less than" anything */
     int p = 0;
     bool dup = false;
     if (valid) x = own.mx(idx);
+#ifndef PSD_RANK_BY_LDS
+    /* Every end is in a register of its lane (f1's in lanes 0-31, f2's in lanes 32-63), so the
+     * other list's ends are broadcast with v_readlane instead of read from LDS: four
+     * instructions per end and no address arithmetic.  Both halves count against every
+     * broadcast end; each keeps the count it needs. */
+    int p_vs_f2 = 0, p_vs_f1 = 0;
+    /* four ends per trip (a loop with cross-lane reads is not unrolled by the compiler); the
+     * lanes read beyond the list hold +Inf */
+    for (int j = 0; j < n2; j += 4) {
+      p_vs_f2 += rdlane_d(x, 32 + j) < x ? 1 : 0;
+      p_vs_f2 += rdlane_d(x, 33 + j) < x ? 1 : 0;
+      p_vs_f2 += rdlane_d(x, 34 + j) < x ? 1 : 0;
+      p_vs_f2 += rdlane_d(x, 35 + j) < x ? 1 : 0;
+    }
+    for (int j = 0; j < n1; j += 4) {
+      p_vs_f1 += rdlane_d(x, j) < x ? 1 : 0;
+      p_vs_f1 += rdlane_d(x, j + 1) < x ? 1 : 0;
+      p_vs_f1 += rdlane_d(x, j + 2) < x ? 1 : 0;
+      p_vs_f1 += rdlane_d(x, j + 3) < x ? 1 : 0;
+    }
+    p = side ? p_vs_f1 : p_vs_f2;
+    /* both lists are sorted and free of repeats: an end also present in the other list is the
+     * other list's end number p */
+    if (valid && p < n_oth) dup = oth.mx(p) == x;
+#else
     /* the other list's ends, eight independent LDS reads per round trip */
     for (int j0 = 0; j0 < n_oth; j0 += 8) {
       double v[8];
@@ -1692,6 +1718,7 @@ PSD_D int min_env_impl(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, i
         }
       }
     }
+#endif
     unsigned long long md = ballot(dup);
     const unsigned long long half = side ? (md >> 32) : (md & 0xffffffffull);
     if (valid && !(side && dup)) {

@@ -263,6 +263,8 @@ struct psd_problem_set {
   unsigned long long arena_used = 0;  /* pieces handed out by the last solve */
   long long dp_bins = 0;
   int spill_slots = 0;
+  int ckpt_interval = 0;                 /* 0 = full store */
+  unsigned long long ckpt_pieces_per_fn = 0; /* region sizing of the checkpointed store */
   psd::DeviceArgs d{};
   hipStream_t stream = nullptr;
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -506,7 +508,7 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
     max_lm[c] = mx;
   }
   s->total_bins = off;
-  long long fn_off = 0, seg_off = 0, dp_bins = 0;
+  long long dp_bins = 0;
   for (int p = 0; p < n_problems; p++) {
     int c = problem_contig[p];
     if (c < 0 || c >= n_contigs) {
@@ -514,18 +516,51 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
       peakseg_hip_problem_set_destroy(s);
       return ERROR_DEVICE_SOLVER;
     }
+    dp_bins += s->contig_n[(size_t)c];
+  }
+  /* Store mode.  Full store: every cost function's backtrack record stays in HBM, as the
+   * reference keeps them on disk (about 24 + 40 P bytes per data point and penalty).
+   * Checkpointed store: only a checkpoint every K data points and the
+   * records of one block of K at a time; the decoding recomputes the blocks it walks through.
+   * Chosen when the full store would not fit (free HBM / PEAKSEG_HIP_MAX_BYTES), or forced
+   * with PEAKSEG_HIP_CHECKPOINT=K. */
+  double per_fn = 16.0;
+  if (const char *e = getenv("PEAKSEG_HIP_PIECES_PER_FUNCTION")) {
+    double v = atof(e);
+    if (v >= 1.0) per_fn = v;
+  }
+  s->max_bytes = env_bytes("PEAKSEG_HIP_MAX_BYTES");
+  int K = 0;
+  if (const char *e = getenv("PEAKSEG_HIP_CHECKPOINT")) K = atoi(e);
+  if (K == 0 && arena_pieces == 0 && !getenv("PEAKSEG_HIP_NO_CHECKPOINT")) {
+    /* what the full store needs at a typical 8 pieces per function, with the tables */
+    const double need = (double)dp_bins * (2.0 * 8.0 * 20.0 + 16.0 + 12.0);
+    size_t free_b = 0, total_b = 0;
+    double room = 1e30;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) room = (double)free_b * 0.9;
+    if (s->max_bytes && (double)s->max_bytes < room) room = (double)s->max_bytes;
+    if (need > room) K = 2048;
+  }
+  if (K < 0) K = 0;
+  if (K > 0 && K < 16) K = 16;
+  s->ckpt_interval = K;
+  long long fn_off = 0, seg_off = 0, ckpt_off = 0;
+  std::vector<long long> prob_ckpt_off;
+  for (int p = 0; p < n_problems; p++) {
+    int c = problem_contig[p];
+    const long long n = s->contig_n[(size_t)c];
     s->prob_contig.push_back(c);
     s->prob_penalty.push_back(problem_penalty[p]);
     s->prob_fn_off.push_back(fn_off);
     s->prob_seg_off.push_back(seg_off);
-    fn_off += 2ll * s->contig_n[c];
-    seg_off += s->contig_n[c] + 1;
-    dp_bins += s->contig_n[c];
+    prob_ckpt_off.push_back(ckpt_off);
+    fn_off += K > 0 ? 2ll * (K + 1) : 2ll * n;
+    seg_off += n + 1;
+    if (K > 0) ckpt_off += (n - 1) / K;
   }
   s->fn_total = fn_off;
   s->seg_total = seg_off;
   s->dp_bins = dp_bins;
-  s->max_bytes = env_bytes("PEAKSEG_HIP_MAX_BYTES");
   /* workgroups are dispatched in index order: start the longest problems first so that a
    * set of unequal contigs does not end with one long problem running alone */
   std::vector<int> order((size_t)n_problems);
@@ -553,9 +588,24 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
       (st = dev_alloc(s, const_cast<psd::DeviceArgs **>(&d.self), (size_t)1)) ||
       (st = dev_alloc(s, &d.fn_ref, (size_t)fn_off)) ||
       (st = dev_alloc(s, &d.seg_start, (size_t)seg_off)) ||
-      (st = dev_alloc(s, &d.seg_mean, (size_t)seg_off))) {
+      (st = dev_alloc(s, &d.seg_mean, (size_t)seg_off)) ||
+      (st = dev_upload(s, &d.prob_ckpt_off, prob_ckpt_off))) {
     peakseg_hip_problem_set_destroy(s);
     return st;
+  }
+  d.ckpt_interval = K;
+  d.ckpt_cap = psd::lat::LDS_CAP;
+  d.ckpt_region = 0;
+  d.ckpt_f64 = nullptr;
+  d.ckpt_i32 = nullptr;
+  if (K > 0) {
+    const size_t cap = (size_t)d.ckpt_cap;
+    const size_t slots = (size_t)(ckpt_off > 0 ? ckpt_off : 1);
+    if ((st = dev_alloc(s, &d.ckpt_f64, slots * (2 + 12 * cap))) ||
+        (st = dev_alloc(s, &d.ckpt_i32, slots * (2 + 2 * cap)))) {
+      peakseg_hip_problem_set_destroy(s);
+      return st;
+    }
   }
   /* spill pool for functions that outgrow LDS (adversarial data): PEAKSEG_HIP_SPILL_CAP pieces
    * per list (default 16384, at most 32767: the interval table packs two indices into an int;
@@ -591,12 +641,14 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
    * reports PST_ARENA_FULL. */
   s->arena_auto = arena_pieces == 0;
   unsigned long long want = arena_pieces;
-  if (s->arena_auto) {
-    double per_fn = 16.0;
-    if (const char *e = getenv("PEAKSEG_HIP_PIECES_PER_FUNCTION")) {
-      double v = atof(e);
-      if (v >= 1.0) per_fn = v;
-    }
+  if (K > 0) {
+    /* one region per chain and problem: the records of K + 1 data points */
+    s->ckpt_pieces_per_fn = (unsigned long long)(per_fn * 2.0);
+    if (s->ckpt_pieces_per_fn < 8) s->ckpt_pieces_per_fn = 8;
+    d.ckpt_region = (unsigned long long)(K + 1) * s->ckpt_pieces_per_fn;
+    want = d.ckpt_region * 2ull * (unsigned long long)n_problems;
+    s->arena_auto = true;
+  } else if (s->arena_auto) {
     want = (unsigned long long)((double)dp_bins * 2.0 * per_fn);
     unsigned long long fit = arena_fit(s);
     if (want > fit) want = fit;
@@ -696,7 +748,12 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
       /* grow and rerun the whole set: at least twice the size, and what the problems' progress
        * says the whole set needs (pieces handed out so far / share of the data points done) */
       unsigned long long bigger = s->arena_pieces * 2ull;
-      {
+      if (s->ckpt_interval > 0) {
+        /* checkpointed store: a block's records outgrew a wave's region -- twice the region */
+        s->ckpt_pieces_per_fn *= 2ull;
+        s->d.ckpt_region = (unsigned long long)(s->ckpt_interval + 1) * s->ckpt_pieces_per_fn;
+        bigger = s->d.ckpt_region * 2ull * (unsigned long long)s->n_problems;
+      } else {
         double done = 0.0, all = 0.0;
         for (int p = 0; p < s->n_problems; p++) {
           const double n = (double)s->contig_n[(size_t)s->prob_contig[(size_t)p]];
@@ -727,8 +784,14 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
   for (int p = 0; p < s->n_problems; p++) {
     const psd::ProbResult &r = s->results[(size_t)p];
     if (r.status != 0 && first == 0) {
-      set_error("problem %d: kernel status %d (wave error bits %d) at data point %d", p, r.status,
-                r.wave_err, r.step_reached);
+      if (r.status == psd::PST_CKPT_SPILL) {
+        set_error("problem %d: a cost function outgrew LDS at a checkpoint (data point %d); the "
+                  "checkpointed store cannot hold it -- rerun with the full store "
+                  "(PEAKSEG_HIP_NO_CHECKPOINT=1)", p, r.step_reached);
+      } else {
+        set_error("problem %d: kernel status %d (wave error bits %d) at data point %d", p,
+                  r.status, r.wave_err, r.step_reached);
+      }
       first = ERROR_DEVICE_SOLVER;
     }
   }
@@ -769,9 +832,14 @@ extern "C" int peakseg_hip_problem_set_segments(psd_problem_set *s, int p, int c
   return r.n_segments;
 }
 
+extern "C" int peakseg_hip_problem_set_checkpoint_interval(psd_problem_set *s) {
+  return s ? s->ckpt_interval : 0;
+}
+
 extern "C" int peakseg_hip_problem_set_export_db(psd_problem_set *s, int p, const int *chromEnd,
                                                  const char *path) {
   if (!s || !s->solved || p < 0 || p >= s->n_problems) return -1;
+  if (s->ckpt_interval > 0) return -1; /* checkpointed store: the functions were not all kept */
   int N = s->contig_n[(size_t)s->prob_contig[(size_t)p]];
   std::vector<unsigned long long> ref((size_t)2 * N);
   if (hipMemcpy(ref.data(), s->d.fn_ref + s->prob_fn_off[(size_t)p], ref.size() * 8,

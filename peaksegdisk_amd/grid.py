@@ -75,6 +75,11 @@ class ProblemSet:
         return int(self._lib.peakseg_hip_problem_set_bytes(self._h))
 
     @property
+    def checkpoint_interval(self):
+        """0: every cost function is kept in HBM; K > 0: checkpointed store (recompute)."""
+        return int(self._lib.peakseg_hip_problem_set_checkpoint_interval(self._h))
+
+    @property
     def arena_bytes_used(self):
         """bytes of the arena the last solve() handed out"""
         return int(self._lib.peakseg_hip_problem_set_arena_bytes_used(self._h))

@@ -188,3 +188,12 @@ def test_emu_dir_batch_cache_and_timing(psd, oracle_det, tmp_path):
 
 def test_emu_spill_pool_and_arena_regrowth(psd, oracle_det, tmp_path, monkeypatch):
     gp2.test_spill_pool_and_arena_regrowth(psd, oracle_det, tmp_path, monkeypatch, 700)
+
+
+def test_emu_checkpointed_store(psd, oracle_det, tmp_path, monkeypatch):
+    gp2.test_checkpointed_store_equals_full_store(psd, oracle_det, tmp_path, monkeypatch, 1500,
+                                                  (16, 100, 5000))
+
+
+def test_emu_checkpointed_store_limits(psd, tmp_path, monkeypatch):
+    gp2.test_checkpointed_store_region_regrowth_and_limits(psd, tmp_path, monkeypatch, 1500, 0)

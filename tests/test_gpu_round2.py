@@ -487,3 +487,116 @@ def test_throughput_set_every_contig_vs_oracle(psd, tmp_path):
             assert loss[5] == "%.20g" % r.best_cost and float(loss[9]) == r.max_intervals
             assert float(loss[8]) == r.total_intervals / (2.0 * len(cnt))
     pset.close()
+
+
+@GPU
+def test_checkpointed_store_equals_full_store(psd, oracle_det, tmp_path, monkeypatch, n_bins=20000,
+                                              intervals=(16, 100, 2048, 50000)):
+    """with PEAKSEG_HIP_CHECKPOINT=K the forward pass keeps a checkpoint
+    every K data points instead of every cost function, and the decoding recomputes the blocks
+    it walks through.  Segment tables, losses and interval statistics must equal the full
+    store's bit for bit (and the oracle's files), for block sizes below, around and above the
+    segment lengths, in both kernel builds; the HBM held shrinks accordingly."""
+    from peaksegdisk_amd import ProblemSet, synthetic
+    cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=11)
+    w = (ce - cs).astype(np.int32)
+    pens = ["0", "0.3", "25", "800", "20000", "1000000"]
+    problems = [(0, float(p)) for p in pens]
+    monkeypatch.setenv("PEAKSEG_HIP_NO_CHECKPOINT", "1")
+    full = ProblemSet([(cnt, w)], problems)
+    full.solve()
+    assert full.checkpoint_interval == 0
+    want = []
+    for i in range(len(pens)):
+        r = full.result(i)
+        assert r.status == 0
+        s0, m0 = full.segments(i)
+        want.append((r.n_segments, r.n_equality_constraints, r.max_intervals, r.total_intervals,
+                     r.best_cost, s0.copy(), m0.copy()))
+    full_bytes = full.hbm_bytes
+    full.close()
+    monkeypatch.delenv("PEAKSEG_HIP_NO_CHECKPOINT")
+    bg = str(tmp_path / "coverage.bedGraph")
+    synthetic.write_bedgraph(bg, cs, ce, cnt)
+    for K in intervals:
+        for build in ("lat", "thr"):
+            monkeypatch.setenv("PEAKSEG_HIP_CHECKPOINT", str(K))
+            monkeypatch.setenv("PEAKSEG_HIP_VARIANT", build)
+            ck = ProblemSet([(cnt, w)], problems)
+            ck.solve()
+            assert ck.checkpoint_interval == K and ck.kernel_build == build
+            for i in range(len(pens)):
+                r = ck.result(i)
+                assert r.status == 0, (K, build, pens[i], r.kernel_status)
+                s1, m1 = ck.segments(i)
+                got = (r.n_segments, r.n_equality_constraints, r.max_intervals, r.total_intervals,
+                       r.best_cost)
+                assert got == want[i][:5], (K, build, pens[i])
+                assert np.array_equal(s1, want[i][5]), (K, build, pens[i])
+                assert np.array_equal(m1.view(np.uint64), want[i][6].view(np.uint64))
+            if K == 2048:
+                assert ck.hbm_bytes < full_bytes
+            ck.close()
+    monkeypatch.delenv("PEAKSEG_HIP_CHECKPOINT")
+    monkeypatch.delenv("PEAKSEG_HIP_VARIANT")
+    # against the oracle's files as well (the full store was; this closes the loop)
+    for i in (1, 3):
+        assert oracle_det.solve(bg, pens[i]) == 0
+        segs = read_segments("%s_penalty=%s_segments.bed" % (bg, pens[i]))
+        assert [s[1] for s in segs] == [int(cs[0]) if q < 0 else int(ce[q]) for q in want[i][5]]
+
+
+@GPU
+def test_checkpointed_store_region_regrowth_and_limits(psd, tmp_path, monkeypatch, n_bins=6000,
+                                                       auto_bins=200000):
+    """A block whose records outgrow the wave's region makes the host double the regions and
+    rerun; a function that has outgrown LDS at a checkpoint is refused with a clear message
+    (the checkpointed store keeps LDS-sized functions only); a memory cap that the full store
+    would exceed selects the checkpointed store by itself."""
+    from peaksegdisk_amd import ProblemSet, synthetic
+    cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=12)
+    w = (ce - cs).astype(np.int32)
+    monkeypatch.setenv("PEAKSEG_HIP_NO_CHECKPOINT", "1")
+    full = ProblemSet([(cnt, w)], [(0, 500.0)])
+    full.solve()
+    want = full.segments(0)
+    full.close()
+    monkeypatch.delenv("PEAKSEG_HIP_NO_CHECKPOINT")
+    monkeypatch.setenv("PEAKSEG_HIP_CHECKPOINT", "256")
+    monkeypatch.setenv("PEAKSEG_HIP_PIECES_PER_FUNCTION", "1")  # regions far too small
+    ck = ProblemSet([(cnt, w)], [(0, 500.0)])
+    ck.solve()
+    got = ck.segments(0)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.uint64),
+                                                              want[1].view(np.uint64))
+    ck.close()
+    monkeypatch.delenv("PEAKSEG_HIP_PIECES_PER_FUNCTION")
+    # adversarial data: functions of hundreds of pieces at the checkpoints
+    c2s, c2e, c2 = synthetic.increasing_coverage(3000)
+    bad = ProblemSet([(c2, (c2e - c2s).astype(np.int32))], [(0, 100.0)])
+    with pytest.raises(RuntimeError, match="outgrew LDS at a checkpoint"):
+        bad.solve()
+    bad.close()
+    monkeypatch.delenv("PEAKSEG_HIP_CHECKPOINT")
+    if not auto_bins:
+        return
+    # automatic choice under a cap: 200 k bins x 4 penalties need ~280 MB in full (estimate:
+    # 348 B per bin and penalty), about 40 MB checkpointed
+    cs, ce, cnt = synthetic.poisson_coverage(auto_bins, seed=13)
+    w = (ce - cs).astype(np.int32)
+    problems = [(0, p) for p in (0.5, 30.0, 900.0, 40000.0)]
+    full = ProblemSet([(cnt, w)], problems)
+    assert full.checkpoint_interval == 0
+    full.solve()
+    want = [full.segments(i) for i in range(4)]
+    full_bytes = full.hbm_bytes
+    full.close()
+    monkeypatch.setenv("PEAKSEG_HIP_MAX_BYTES", "100M")
+    auto = ProblemSet([(cnt, w)], problems)
+    assert auto.checkpoint_interval > 0 and auto.hbm_bytes < 100 * 2 ** 20 < full_bytes
+    auto.solve()
+    for i in range(4):
+        got = auto.segments(i)
+        assert np.array_equal(got[0], want[i][0])
+        assert np.array_equal(got[1].view(np.uint64), want[i][1].view(np.uint64))
+    auto.close()
