@@ -566,8 +566,11 @@ PSD_COLD_DEV double ckpt_cum_weight(const DeviceArgs &a, int p, int k) {
 #else
 #define PSD_KERNEL_OCC
 #endif
-__global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_kernel(
-    DeviceArgs a) {
+/* The kernel body.  CKPT = false: the full store, one pass (everything about passes and
+ * checkpoints below folds away: the loop is the one the latency numbers were tuned on);
+ * CKPT = true: the checkpointed store's passes. */
+template <bool CKPT>
+PSD_D void forward_body(const DeviceArgs &a) {
   const int p = a.prob_order[blockIdx.x];
   const int chain = uniform_i(wave_id()) & 1; /* uniform per wave: say so (scalar branches) */
   const int lane = lane_id();
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
    * checkpoint every K data points, then, led by the decoding, one pass per block of K data
    * points that holds a segment end, from that block's checkpoint and with the records kept
    * in this wave's region of the arena. */
-  const int K = a.ckpt_interval;
+  const int K = CKPT ? a.ckpt_interval : 0;
   const unsigned long long fn_stride = K > 0 ? (unsigned long long)K + 1ull : (unsigned long long)N;
   const unsigned long long fn_up = (unsigned long long)a.prob_fn_off[p];
   const unsigned long long fn_down = fn_up + fn_stride;
@@ -653,7 +656,8 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
   for (;;) { /* passes */
   for (t = t_lo; t < t_hi; t++) {
     PSD_PROF_T0();
-    if ((t & 63) == 0 || t == t_lo) { /* coalesced read of the next 64 data points */
+    if (!CKPT) cur.store = 1; /* known to the compiler even after a cold call returned the cursor */
+    if ((t & 63) == 0 || (CKPT && t == t_lo)) { /* coalesced read of the next 64 data points */
       int tt = (t & ~63) + lane;
       cnt_reg = tt < N ? count[tt] : 0;
       wt_reg = tt < N ? weight[tt] : 0;
@@ -748,7 +752,7 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
       break;
     }
     if (status != 0) break;
-    if (forward) {
+    if (!CKPT || forward) {
       total_intervals += (unsigned long long)n_new;
       if (max_intervals < n_new) max_intervals = n_new;
       if (in_hbm) spill_steps++;
@@ -756,7 +760,7 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
     cum_weight_i = cum_weight_new;
     cum_weight_prev_i = cum_weight_i;
     b = nb;
-    if (t == next_ckpt) { /* checkpointed store, forward pass: keep the two live functions */
+    if (CKPT && t == next_ckpt) { /* forward pass: keep the two live functions */
       if (in_hbm) {
         status = PST_CKPT_SPILL; /* both chains: in_hbm is the same in the two waves */
         break;
@@ -765,7 +769,7 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
       next_ckpt += K;
     }
   }
-  if (forward) step_reached = t;
+  if (!CKPT || forward) step_reached = t;
   if (status != 0) break;
   /* ---- after a pass ---- */
   if (forward) {
@@ -796,7 +800,7 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
      * -- nothing but the one-segment model's only row */
     backtrack_wave(a, p, N, bt, fn_up, fn_down, t_origin, (K > 0 && forward) ? N : t_lo);
   }
-  if (K == 0) break;
+  if (!CKPT || K == 0) break;
   /* checkpointed store: which block holds the next segment end?  (-1: decoding complete) */
   if (chain == 1 && lane == 0) {
     int c = -1;
@@ -856,6 +860,16 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_k
     r.spill_steps = spill_steps;
     if (lane == 0) a.result[p] = r;
   }
+}
+
+__global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_kernel(
+    DeviceArgs a) {
+  forward_body<false>(a);
+}
+/* the same for problem sets that use the checkpointed store (a.ckpt_interval > 0) */
+__global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_ckpt_kernel(
+    DeviceArgs a) {
+  forward_body<true>(a);
 }
 
 __global__ void math_probe_kernel(int op, int n, const double *x, double *y) {

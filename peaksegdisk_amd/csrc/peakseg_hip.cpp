@@ -697,12 +697,22 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
     HIP_TRY(hipMemcpyAsync(const_cast<psd::DeviceArgs *>(s->d.self), &s->d, sizeof(psd::DeviceArgs),
                            hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipEventRecord(s->ev[0], s->stream));
-    if (s->throughput)
-      hipLaunchKernelGGL(psd::thr::fpop_forward_kernel, dim3((unsigned)s->n_problems),
-                         dim3(psd::thr::FORWARD_THREADS), 0, s->stream, s->d);
-    else
-      hipLaunchKernelGGL(psd::lat::fpop_forward_kernel, dim3((unsigned)s->n_problems),
-                         dim3(psd::lat::FORWARD_THREADS), 0, s->stream, s->d);
+    const dim3 grid((unsigned)s->n_problems);
+    if (s->throughput) {
+      if (s->ckpt_interval > 0)
+        hipLaunchKernelGGL(psd::thr::fpop_forward_ckpt_kernel, grid,
+                           dim3(psd::thr::FORWARD_THREADS), 0, s->stream, s->d);
+      else
+        hipLaunchKernelGGL(psd::thr::fpop_forward_kernel, grid, dim3(psd::thr::FORWARD_THREADS),
+                           0, s->stream, s->d);
+    } else {
+      if (s->ckpt_interval > 0)
+        hipLaunchKernelGGL(psd::lat::fpop_forward_ckpt_kernel, grid,
+                           dim3(psd::lat::FORWARD_THREADS), 0, s->stream, s->d);
+      else
+        hipLaunchKernelGGL(psd::lat::fpop_forward_kernel, grid, dim3(psd::lat::FORWARD_THREADS),
+                           0, s->stream, s->d);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[1], s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));

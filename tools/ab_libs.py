@@ -25,8 +25,29 @@ for k in range(args.contigs):
     contigs.append((cnt, (ce - cs).astype(np.int32)))
 pens = synthetic.penalty_grid(64)
 problems = [(k, float(p)) for k in range(args.contigs) for p in pens]
+
+
+def bind(path):
+    """Older builds lack the newest entry points: bind what ProblemSet needs."""
+    lib = ctypes.CDLL(os.path.abspath(path))
+    try:
+        return _native.declare(lib)
+    except AttributeError:
+        c = ctypes
+        lib.peakseg_hip_problem_set_create.argtypes = [
+            c.c_int, c.c_int, c.POINTER(c.c_int), c.POINTER(c.c_void_p), c.POINTER(c.c_void_p),
+            c.c_int, c.POINTER(c.c_int), c.POINTER(c.c_double), c.c_ulonglong,
+            c.POINTER(c.c_void_p)]
+        lib.peakseg_hip_problem_set_solve.argtypes = [
+            c.c_void_p, c.POINTER(c.c_float), c.POINTER(c.c_float)]
+        lib.peakseg_hip_problem_set_destroy.argtypes = [c.c_void_p]
+        lib.peakseg_hip_problem_set_destroy.restype = None
+        lib.peakseg_hip_last_error.restype = c.c_char_p
+        return lib
+
+
 for name in args.libs:
-    lib = _native.declare(ctypes.CDLL(os.path.abspath(name)))
+    lib = bind(name)
     ps = ProblemSet(contigs, problems, lib=lib)
     ps.solve()
     f = [ps.solve()[0] for _ in range(2)]
