@@ -95,3 +95,66 @@ PSD_HD static inline double PSD_FN(psd_log)(double x) {
   }
   return y;
 }
+
+/* Two (three) independent evaluations in one basic block.  Each psd_exp / psd_log ends in the
+ * branch to its rare-argument path, and a branch is a scheduling barrier: two calls in a row
+ * run one after the other although neither needs the other's result.  A wave on its own issues
+ * a dependent fp64 instruction every 7-9 cycles but an independent one every 4, so evaluating
+ * them interleaved, with ONE rare-argument branch for all, takes little more than one of them.
+ * Results are those of the single functions, bit for bit (pure functions of the argument). */
+PSD_HD static inline void PSD_FN(psd_exp2)(double x0, double x1, double *y0, double *y1) {
+  long long k0, k1;
+  double h0, h1;
+  double t0 = PSD_FN(psd_exp_core)(x0, &k0, &h0);
+  double t1 = PSD_FN(psd_exp_core)(x1, &k1, &h1);
+  double s0 = psd_u2d(psd_d2u(h0) + ((uint64_t)(k0 >> 7) << 52));
+  double s1 = psd_u2d(psd_d2u(h1) + ((uint64_t)(k1 >> 7) << 52));
+  double r0 = psd_fma(s0, t0, s0), r1 = psd_fma(s1, t1, s1);
+  const int rare0 = !(__builtin_fabs(x0) <= 708.0), rare1 = !(__builtin_fabs(x1) <= 708.0);
+  if (PSD_ANY_LANE(rare0 | rare1)) {
+    const double q0 = psd_exp_slow(x0), q1 = psd_exp_slow(x1);
+    r0 = rare0 ? q0 : r0;
+    r1 = rare1 ? q1 : r1;
+  }
+  *y0 = r0;
+  *y1 = r1;
+}
+
+PSD_HD static inline void PSD_FN(psd_log2)(double x0, double x1, double *y0, double *y1) {
+  const uint64_t u0 = psd_d2u(x0), u1 = psd_d2u(x1);
+  double r0 = PSD_FN(psd_log_core)(u0, 0), r1 = PSD_FN(psd_log_core)(u1, 0);
+  const int rare0 = !((uint32_t)(u0 >> 32) - 0x00100000u < 0x7fe00000u);
+  const int rare1 = !((uint32_t)(u1 >> 32) - 0x00100000u < 0x7fe00000u);
+  if (PSD_ANY_LANE(rare0 | rare1)) {
+    const double q0 = psd_log_slow(x0), q1 = psd_log_slow(x1);
+    r0 = rare0 ? q0 : r0;
+    r1 = rare1 ? q1 : r1;
+  }
+  *y0 = r0;
+  *y1 = r1;
+}
+
+/* exp(x0), exp(x1), log(z) */
+PSD_HD static inline void PSD_FN(psd_exp2_log)(double x0, double x1, double z, double *y0,
+                                               double *y1, double *lz) {
+  long long k0, k1;
+  double h0, h1;
+  double t0 = PSD_FN(psd_exp_core)(x0, &k0, &h0);
+  double t1 = PSD_FN(psd_exp_core)(x1, &k1, &h1);
+  const uint64_t uz = psd_d2u(z);
+  double rz = PSD_FN(psd_log_core)(uz, 0);
+  double s0 = psd_u2d(psd_d2u(h0) + ((uint64_t)(k0 >> 7) << 52));
+  double s1 = psd_u2d(psd_d2u(h1) + ((uint64_t)(k1 >> 7) << 52));
+  double r0 = psd_fma(s0, t0, s0), r1 = psd_fma(s1, t1, s1);
+  const int rare0 = !(__builtin_fabs(x0) <= 708.0), rare1 = !(__builtin_fabs(x1) <= 708.0);
+  const int rarez = !((uint32_t)(uz >> 32) - 0x00100000u < 0x7fe00000u);
+  if (PSD_ANY_LANE(rare0 | rare1 | rarez)) {
+    const double q0 = psd_exp_slow(x0), q1 = psd_exp_slow(x1), qz = psd_log_slow(z);
+    r0 = rare0 ? q0 : r0;
+    r1 = rare1 ? q1 : r1;
+    rz = rarez ? qz : rz;
+  }
+  *y0 = r0;
+  *y1 = r1;
+  *lz = rz;
+}

@@ -58,6 +58,20 @@ PSD_D double d_exp(double x) { return psd_exp(x); }
 PSD_D double d_log(double x) { return psd_log(x); }
 #endif
 
+#if defined(PSD_MATH_VK) && defined(__HIP_DEVICE_COMPILE__)
+PSD_D void d_exp2(double x0, double x1, double &y0, double &y1) { psd_exp2_vk(x0, x1, &y0, &y1); }
+PSD_D void d_log2(double x0, double x1, double &y0, double &y1) { psd_log2_vk(x0, x1, &y0, &y1); }
+PSD_D void d_exp2_log(double x0, double x1, double z, double &y0, double &y1, double &lz) {
+  psd_exp2_log_vk(x0, x1, z, &y0, &y1, &lz);
+}
+#else
+PSD_D void d_exp2(double x0, double x1, double &y0, double &y1) { psd_exp2(x0, x1, &y0, &y1); }
+PSD_D void d_log2(double x0, double x1, double &y0, double &y1) { psd_log2(x0, x1, &y0, &y1); }
+PSD_D void d_exp2_log(double x0, double x1, double z, double &y0, double &y1, double &lz) {
+  psd_exp2_log(x0, x1, z, &y0, &y1, &lz);
+}
+#endif
+
 /* fpl:192-197 */
 PSD_D double argmin_mean(const Coef &c) { return -c.Log / c.Linear; }
 

@@ -371,10 +371,30 @@ PSD_D void piece_costs_wave(const L &in, int n, const S &s, LanePiece &P) {
     if (i < n) {
       Coef c = load_coef(in, i);
       double mn = in.mn(i), mx = in.mx(i);
+#ifndef PSD_NO_PAIRED_MATH
+      /* exp(mn), exp(mx) and log(argmin_mean) do not depend on one another: one interleaved
+       * evaluation (peakseg_detmath_core.h, psd_exp2_log) instead of three in a row; the values
+       * are those of get_cost() and piece_opt() */
+      const bool has_opt = c.Log != 0;
+      PieceOpt o = {0.0, 0.0, 0.0, 0.0};
+      if (has_opt) o.mean = argmin_mean(c);
+      double e_mn, e_mx, l_om;
+      d_exp2_log(mn == -PSD_INF ? 0.0 : mn, mx == -PSD_INF ? 0.0 : mx, has_opt ? o.mean : 1.0,
+                 e_mn, e_mx, l_om);
+      double lc = get_cost_e(c, mn, e_mn);
+      double rc = get_cost_e(c, mx, e_mx);
+      if (has_opt) {
+        o.log_mean = l_om;
+        o.cost = get_cost(c, o.log_mean);
+        double loss_without_log_term = c.Linear * o.mean + c.Constant; /* fpl:52-61 */
+        o.cost2 = loss_without_log_term + o.log_mean * c.Log;
+      }
+#else
       double lc = get_cost(c, mn);
       double rc = get_cost(c, mx);
       PieceOpt o = {0.0, 0.0, 0.0, 0.0};
       if (c.Log != 0) o = piece_opt(c);
+#endif
       s.lc(i) = lc;
       s.rc(i) = rc;
       s.om(i) = o.mean;
@@ -1352,28 +1372,48 @@ PSD_D void env_classify_lanes(bool valid, const Coef &c1, const Coef &c2, double
     }
   }
 #endif
-  /* phase A/B: exp(a), exp(b), cost at the mean-space midpoint (fpl:960-961) */
+  /* phases A-D: exp(a), exp(b); the cost at the mean-space midpoint (fpl:960-961); the one log
+   * site for the degenerate crossing and for argmin() of the difference; the optimum of the
+   * difference piece, its end costs, has_two_roots (fpl:1020-1022).  Six transcendentals per
+   * interval, evaluated in three interleaved pairs (the values are those of the single calls):
+   * exp(a) | exp(b), log(midpoint) | log(argmin_mean), exp for the cost at each of the two. */
   double ea = 0.0, eb = 0.0, cost_diff_mid = 0.0;
+  const double larg = degen ? (-d.Constant / d.Linear) : (-d.Log / d.Linear);
+  const bool need_l = degen_root || rootp;
+  double lres = 0.0;
+  PieceOpt o = {0.0, 0.0, 0.0, 0.0};
+  double cost_diff_left = 0.0, cost_diff_right = 0.0;
+  bool two_roots = false;
+#ifndef PSD_NO_PAIRED_MATH
+  if (ballot(act)) {
+    d_exp2((act && a != -PSD_INF) ? a : 0.0, act ? b : 0.0, ea, eb);
+    if (a == -PSD_INF) ea = 0.0; /* exp(-Inf) */
+    double log_mid;
+    d_log2(act ? (eb + ea) / 2 : 1.0, need_l ? larg : 1.0, log_mid, lres);
+    if (!need_l) lres = 0.0;
+    double e_mid, e_opt;
+    d_exp2(log_mid == -PSD_INF ? 0.0 : log_mid, (rootp && lres != -PSD_INF) ? lres : 0.0, e_mid,
+           e_opt);
+    if (act) cost_diff_mid = get_cost_e(d, log_mid, e_mid);
+    if (!act) ea = eb = 0.0;
+    if (rootp) o.cost = get_cost_e(d, lres, e_opt);
+  }
+  PSD_PROF_ADD(PROF_C_MID);
+#else
   if (act) {
     ea = d_exp(a);
     eb = d_exp(b);
     cost_diff_mid = get_cost(d, d_log((eb + ea) / 2));
   }
   PSD_PROF_ADD(PROF_C_MID);
-  /* phase C: one log site for the degenerate crossing and for argmin() of the difference */
-  const double larg = degen ? (-d.Constant / d.Linear) : (-d.Log / d.Linear);
-  double lres = 0.0;
-  /* phase D: optimum of the difference piece, its end costs, has_two_roots (fpl:1020-1022) */
-  PieceOpt o = {0.0, 0.0, 0.0, 0.0};
-  double cost_diff_left = 0.0, cost_diff_right = 0.0;
-  bool two_roots = false;
-  if (degen_root || rootp) lres = d_log(larg);
+  if (need_l) lres = d_log(larg);
+  if (rootp) o.cost = get_cost(d, lres);
+#endif
   if (rootp) {
     cost_diff_left = get_cost_e(d, a, ea);
     cost_diff_right = get_cost_e(d, b, eb);
     o.mean = larg;
     o.log_mean = lres;
-    o.cost = get_cost(d, lres);
     double loss_without_log_term = d.Linear * o.mean + d.Constant;
     o.cost2 = loss_without_log_term + o.log_mean * d.Log;
     two_roots = has_two_roots(d, o, 0.0);

@@ -57,7 +57,7 @@ def test_emu_synthetic(psd, oracle_det, oracle_libm, tmp_path):
 
 
 def test_emu_python_entry_points(psd, tmp_path):
-    gp.test_python_entry_points(psd, tmp_path)
+    gp.test_python_entry_points(psd, tmp_path, with_search=False)
 
 
 def test_emu_adversarial_spill(psd, oracle_det, tmp_path):
@@ -191,8 +191,8 @@ def test_emu_spill_pool_and_arena_regrowth(psd, oracle_det, tmp_path, monkeypatc
 
 
 def test_emu_checkpointed_store(psd, oracle_det, tmp_path, monkeypatch):
-    gp2.test_checkpointed_store_equals_full_store(psd, oracle_det, tmp_path, monkeypatch, 1500,
-                                                  (16, 100, 5000))
+    gp2.test_checkpointed_store_equals_full_store(psd, oracle_det, tmp_path, monkeypatch, 1200,
+                                                  (16, 3000))
 
 
 def test_emu_checkpointed_store_limits(psd, tmp_path, monkeypatch):
