@@ -690,6 +690,10 @@ extern "C" int PeakSegFPOP_sequential_search(const char *problem_dir, int peaks_
       r.total_loss = lr.total_loss;
       r.cached = cached ? 1 : 0;
       n++;
+      if (getenv("PEAKSEG_HIP_TIMING")) /* progress of a long search (stderr is unbuffered) */
+        fprintf(stderr, "peakseg_hip timing: search model %d: penalty=%s peaks=%d%s, %.1f s so far "
+                        "in the kernel\n", n, r.penalty_str, r.peaks, cached ? " (cached)" : "",
+                rd.kernel_s);
     }
     if (n_rows) *n_rows = n;
     if (iteration == 1) {

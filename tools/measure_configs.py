@@ -7,9 +7,11 @@ not bench lines; these numbers go into DESIGN.md / profiles/):
        launch -- the regime where the chip is actually filled
   c5   adversarial increasing counts (configs[4], vignettes/Worst_case.Rmd) at penalty 100:
        lists far beyond LDS -> HBM spill path
-  c3   sequentialSearch_dir (configs[2]) on one synthetic contig through the file-level API
+  c3   sequentialSearch_dir (configs[2]) on one synthetic contig through the resident native
+       driver, optionally checked against a trace of the same search driven by the CPU oracle
+  (configs[3] itself is `python bench.py --mode grid`)
 
-usage: python tools/measure_configs.py c4|c5|c3 [size]
+usage: python tools/measure_configs.py c4|c5 [size] | c3 bins target_peaks [seed [trace]]
 """
 import json
 import os
@@ -58,29 +60,55 @@ def c5(n=100000):
     return out
 
 
-def c3(n=2000000, peaks=300):
+def c3(n=2000000, peaks=300, seed=3, trace=None):
+    """sequentialSearch_dir through the resident native driver.  trace: a log of the same search
+    driven by the CPU oracle (tools: one dict per model, as profiles/r02/
+    config3_cpu_trace_1e7_det_oracle.log); the models visited must then equal its first ones,
+    penalty strings included."""
+    import ast
     import peaksegdisk_amd as psd
     from peaksegdisk_amd import synthetic
-    cs, ce, cnt = synthetic.poisson_coverage(n, seed=3)
+    cs, ce, cnt = synthetic.poisson_coverage(n, seed=seed)
     d = tempfile.mkdtemp(prefix="psd_c3_")
     pdir = os.path.join(d, "chrSynth-0-%d" % int(ce[-1]))
     os.makedirs(pdir)
-    synthetic.write_bedgraph(os.path.join(pdir, "coverage.bedGraph"), cs, ce, cnt)
+    bg = os.path.join(pdir, "coverage.bedGraph")
+    with open(bg, "w") as f:
+        for o in range(0, n, 500000):
+            f.write("".join("chrSynth\t%d\t%d\t%d\n" % t for t in zip(
+                cs[o:o + 500000].tolist(), ce[o:o + 500000].tolist(),
+                cnt[o:o + 500000].tolist())))
+    os.environ["PEAKSEG_HIP_TIMING"] = "1"
     t0 = time.time()
     fit = psd.sequentialSearch_dir(pdir, peaks)
     wall = time.time() - t0
     others = fit.others
-    return {"config": "c3", "bins": n, "target_peaks": peaks,
-            "found_peaks": int(fit.loss["peaks"].iloc[0]), "dp_runs": int(len(others)),
-            "penalties": [float(x) for x in others["penalty"]],
-            "peaks_by_run": [int(x) for x in others["peaks"]],
-            "seconds_by_run": [float(x) for x in others["seconds"]], "wall_s": wall,
-            "bins_per_s_over_all_runs": n * len(others) / wall}
+    out = {"config": "c3", "bins": n, "target_peaks": peaks,
+           "found_peaks": int(fit.loss["peaks"].iloc[0]), "models": int(len(others)),
+           "penalties": [psd.paste(float(x)) for x in others["penalty"]],
+           "peaks_by_model": [int(x) for x in others["peaks"]],
+           "seconds_by_model": [float(x) for x in others["seconds"]], "wall_s": wall,
+           "dp_bins_per_s": n * (len(others) - 1) / wall}
+    if trace:
+        want = [ast.literal_eval(ln) for ln in open(trace) if ln.startswith("{")]
+        k = len(out["penalties"])
+        out["matches_cpu_oracle_trace"] = (
+            out["penalties"] == [m["penalty"] for m in want[:k]] and
+            out["peaks_by_model"] == [m["peaks"] for m in want[:k]])
+        out["cpu_oracle_seconds_by_model"] = [round(m["seconds"], 1) for m in want[:k]]
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
+    return out
 
 
 if __name__ == "__main__":
     which = sys.argv[1]
-    arg = [float(a) for a in sys.argv[2:]]
-    fn = {"c4": c4, "c5": c5, "c3": c3}[which]
-    res = fn(*[int(a) if which != "c4" else a for a in arg])
+    if which == "c3":  # c3 bins target_peaks seed [trace]
+        a = sys.argv[2:]
+        res = c3(int(float(a[0])), int(a[1]), int(a[2]) if len(a) > 2 else 3,
+                 a[3] if len(a) > 3 else None)
+    else:
+        arg = [float(a) for a in sys.argv[2:]]
+        fn = {"c4": c4, "c5": c5}[which]
+        res = fn(*[int(a) if which != "c4" else a for a in arg])
     print(json.dumps(res))
