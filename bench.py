@@ -230,6 +230,12 @@ def main():
         else:
             dist.init_process_group(backend)
         assert dist.get_world_size() == args.gpus
+        if not os.environ.get("PSD_BENCH_TEST_LIB"):
+            # under the driver's torchrun the library is normally built already (build());
+            # if it is not, one rank builds it and the others wait
+            if rank == 0 and not os.path.exists(entry.LIB):
+                entry.build_hip()
+            dist.barrier()
     device = local_rank if (world > 1 and on_gpu) else 0
     from peaksegdisk_amd import _native
     if not on_gpu and os.environ.get("PSD_BENCH_TEST_LIB"):

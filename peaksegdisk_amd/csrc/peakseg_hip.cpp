@@ -272,6 +272,10 @@ struct psd_problem_set {
   bool solved = false;
   int n_cu = 0;            /* compute units of the device */
   bool throughput = false; /* which kernel build the last solve used */
+  int n_lat_mixed = 0;     /* mixed launch: this many (longest) problems ran on the latency build */
+  std::vector<int> order;  /* problems, longest contig first */
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev2 = nullptr;
   std::vector<void *> allocs;
   unsigned long long bytes = 0;
 };
@@ -433,11 +437,14 @@ extern "C" void peakseg_hip_problem_set_destroy(psd_problem_set *s) {
   for (void *q : s->allocs) (void)hipFree(q);
   for (auto &e : s->ev)
     if (e) (void)hipEventDestroy(e);
+  if (s->ev2) (void)hipEventDestroy(s->ev2);
   if (s->stream) (void)hipStreamDestroy(s->stream);
+  if (s->stream2) (void)hipStreamDestroy(s->stream2);
   delete s;
 }
 
 extern "C" const char *peakseg_hip_problem_set_kernel_build(psd_problem_set *s) {
+  if (s->throughput && s->n_lat_mixed > 0) return "lat+thr";
   return s->throughput ? "thr" : "lat";
 }
 
@@ -667,7 +674,19 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
           hipSuccess ||
       s->n_cu <= 0)
     s->n_cu = 256;
+  s->order = order;
   hipError_t e = hipStreamCreate(&s->stream);
+#ifdef PSD_EMU
+  if (e == hipSuccess) e = hipStreamCreate(&s->stream2);
+#else
+  if (e == hipSuccess) {
+    /* the latency-build part of a mixed launch must get its CUs before the packed part does */
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    e = hipStreamCreateWithPriority(&s->stream2, hipStreamDefault, hi);
+  }
+#endif
+  if (e == hipSuccess) e = hipEventCreate(&s->ev2);
   for (auto &ev : s->ev)
     if (e == hipSuccess) e = hipEventCreate(&ev);
   if (e != hipSuccess) {
@@ -687,9 +706,44 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
    * other and the throughput build (4 per CU) finishes the set sooner.
    * PEAKSEG_HIP_VARIANT=lat|thr overrides (tests, A/B runs). */
   s->throughput = s->n_problems > s->n_cu;
+  bool forced = false;
   if (const char *e = getenv("PEAKSEG_HIP_VARIANT")) {
-    if (!strcmp(e, "lat")) s->throughput = false;
-    if (!strcmp(e, "thr")) s->throughput = true;
+    if (!strcmp(e, "lat")) s->throughput = false, forced = true;
+    if (!strcmp(e, "thr")) s->throughput = true, forced = true;
+  }
+  /* Mixed launch for sets of unequal contigs that oversubscribe the chip: a problem on the
+   * throughput build advances about 27 k data points per second, on the latency build (a CU of
+   * its own) about 90 k, so the longest problems would decide when the set ends.  The L longest
+   * problems go to the latency build -- launched first, on a stream of its own, one CU each --
+   * and the rest is packed four to a CU on what is left; L minimises the later of the two
+   * predicted ends.  (Equal contigs: L = 0.) */
+  s->n_lat_mixed = 0;
+  if (s->throughput && !forced) {
+    const double lat_rate = 90e3, thr_rate = 27e3, thr_per_cu = 4.0;
+    std::vector<double> len((size_t)s->n_problems);
+    double rest = 0.0;
+    for (int k = 0; k < s->n_problems; k++) {
+      len[(size_t)k] = (double)s->contig_n[(size_t)s->prob_contig[(size_t)s->order[(size_t)k]]];
+      rest += len[(size_t)k];
+    }
+    double best = 1e300;
+    int best_l = 0;
+    const int l_max = s->n_cu - 16 < s->n_problems ? s->n_cu - 16 : s->n_problems - 1;
+    double sum_lat = 0.0;
+    for (int l = 0; l <= l_max; l++) {
+      /* problems [0, l) on the latency build, [l, n) on the throughput build */
+      const double t_lat = l > 0 ? len[0] / lat_rate : 0.0;
+      const double cus = (double)(s->n_cu - l);
+      const double t_thr_work = (rest - sum_lat) / (cus * thr_per_cu * thr_rate);
+      const double t_thr_long = len[(size_t)l] / thr_rate;
+      const double t = std::max(t_lat, std::max(t_thr_work, t_thr_long));
+      if (t < best * 0.98) { /* prefer fewer latency problems unless it clearly pays */
+        best = t;
+        best_l = l;
+      }
+      sum_lat += len[(size_t)l];
+    }
+    s->n_lat_mixed = best_l;
   }
   for (int attempt = 0;; attempt++) {
     HIP_TRY(hipMemsetAsync(s->d.ar_next_chunk, 0, sizeof(unsigned long long), s->stream));
@@ -698,7 +752,29 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
                            hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipEventRecord(s->ev[0], s->stream));
     const dim3 grid((unsigned)s->n_problems);
-    if (s->throughput) {
+    if (s->throughput && s->n_lat_mixed > 0) {
+      /* mixed launch: both kernels index prob_order by their own blockIdx.x */
+      const int L = s->n_lat_mixed;
+      psd::DeviceArgs d_lat = s->d, d_thr = s->d;
+      d_lat.n_problems = L;
+      d_thr.n_problems = s->n_problems - L;
+      d_thr.prob_order = s->d.prob_order + L;
+      HIP_TRY(hipStreamWaitEvent(s->stream2, s->ev[0], 0));
+      if (s->ckpt_interval > 0) {
+        hipLaunchKernelGGL(psd::lat::fpop_forward_ckpt_kernel, dim3((unsigned)L),
+                           dim3(psd::lat::FORWARD_THREADS), 0, s->stream2, d_lat);
+        hipLaunchKernelGGL(psd::thr::fpop_forward_ckpt_kernel, dim3((unsigned)d_thr.n_problems),
+                           dim3(psd::thr::FORWARD_THREADS), 0, s->stream, d_thr);
+      } else {
+        hipLaunchKernelGGL(psd::lat::fpop_forward_kernel, dim3((unsigned)L),
+                           dim3(psd::lat::FORWARD_THREADS), 0, s->stream2, d_lat);
+        hipLaunchKernelGGL(psd::thr::fpop_forward_kernel, dim3((unsigned)d_thr.n_problems),
+                           dim3(psd::thr::FORWARD_THREADS), 0, s->stream, d_thr);
+      }
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(s->ev2, s->stream2));
+      HIP_TRY(hipStreamWaitEvent(s->stream, s->ev2, 0));
+    } else if (s->throughput) {
       if (s->ckpt_interval > 0)
         hipLaunchKernelGGL(psd::thr::fpop_forward_ckpt_kernel, grid,
                            dim3(psd::thr::FORWARD_THREADS), 0, s->stream, s->d);

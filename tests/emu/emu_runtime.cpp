@@ -264,6 +264,7 @@ hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) {
   memset(p, v, n);
   return hipSuccess;
 }
+hipError_t hipStreamWaitEvent(hipStream_t, emu_event *, unsigned) { return hipSuccess; }
 hipError_t hipStreamCreate(hipStream_t *s) {
   *s = nullptr;
   return hipSuccess;

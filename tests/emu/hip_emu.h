@@ -111,6 +111,7 @@ hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t s);
 hipError_t hipStreamCreate(hipStream_t *s);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipStreamWaitEvent(hipStream_t s, struct emu_event *e, unsigned flags);
 hipError_t hipDeviceSynchronize();
 hipError_t hipEventCreate(hipEvent_t *e);
 hipError_t hipEventDestroy(hipEvent_t e);

@@ -197,3 +197,7 @@ def test_emu_checkpointed_store(psd, oracle_det, tmp_path, monkeypatch):
 
 def test_emu_checkpointed_store_limits(psd, tmp_path, monkeypatch):
     gp2.test_checkpointed_store_region_regrowth_and_limits(psd, tmp_path, monkeypatch, 1500, 0)
+
+
+def test_emu_mixed_launch(psd, tmp_path, monkeypatch):
+    gp2.test_mixed_launch_of_unequal_contigs(psd, tmp_path, monkeypatch, 900, 60, 63)

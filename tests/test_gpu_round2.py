@@ -600,3 +600,57 @@ def test_checkpointed_store_region_regrowth_and_limits(psd, tmp_path, monkeypatc
         assert np.array_equal(got[0], want[i][0])
         assert np.array_equal(got[1].view(np.uint64), want[i][1].view(np.uint64))
     auto.close()
+
+
+@GPU
+def test_mixed_launch_of_unequal_contigs(psd, tmp_path, monkeypatch, n_long=6000, n_short=300,
+                                         n_short_contigs=70):
+    """A set that oversubscribes the chip with contigs of very different lengths: the longest
+    problems run on the latency build (a CU each), the rest packed on the throughput build, in
+    one solve ("lat+thr").  Every problem against the oracle's files; the same set forced onto
+    one build gives the same bits."""
+    from peaksegdisk_amd import ProblemSet, synthetic
+    monkeypatch.delenv("PEAKSEG_HIP_VARIANT", raising=False)
+    lens = [n_long, n_long + 500] + [n_short + 3 * k for k in range(n_short_contigs)]
+    pens = ["0.4", "12", "300", "9000"]
+    contigs, data = [], []
+    for k, n in enumerate(lens):
+        cs, ce, cnt = synthetic.poisson_coverage(n, seed=900 + k)
+        contigs.append((cnt, (ce - cs).astype(np.int32)))
+        data.append((cs, ce, cnt))
+    problems = [(k, float(p)) for k in range(len(lens)) for p in pens]
+    assert len(problems) > 256
+    pset = ProblemSet(contigs, problems)
+    pset.solve()
+    assert pset.kernel_build == "lat+thr"
+
+    def oracle_job(k):
+        cs, ce, cnt = data[k]
+        bg = str(tmp_path / ("c%d.bedGraph" % k))
+        synthetic.write_bedgraph(bg, cs, ce, cnt)
+        for pen in pens:
+            run_cli(CLI_DET, bg, pen, bg + ".db")
+        return bg
+    with ThreadPoolExecutor(max_workers=len(os.sched_getaffinity(0))) as pool:
+        bgs = list(pool.map(oracle_job, range(len(lens))))
+    monkeypatch.setenv("PEAKSEG_HIP_VARIANT", "thr")
+    one = ProblemSet(contigs, problems)
+    one.solve()
+    assert one.kernel_build == "thr"
+    for k in range(len(lens)):
+        cs, ce, cnt = data[k]
+        for j, pen in enumerate(pens):
+            i = k * len(pens) + j
+            r = pset.result(i)
+            assert r.status == 0
+            segs = read_segments("%s_penalty=%s_segments.bed" % (bgs[k], pen))
+            start, mean = pset.segments(i)
+            assert [s[1] for s in segs] == [int(cs[0]) if q < 0 else int(ce[q]) for q in start]
+            assert [s[4] for s in segs] == ["%g" % v for v in mean]
+            loss = read_loss("%s_penalty=%s_loss.tsv" % (bgs[k], pen)).split("\t")
+            assert loss[5] == "%.20g" % r.best_cost and float(loss[9]) == r.max_intervals
+            s1, m1 = one.segments(i)
+            assert np.array_equal(start, s1) and np.array_equal(mean.view(np.uint64),
+                                                                m1.view(np.uint64))
+    pset.close()
+    one.close()
