@@ -142,7 +142,7 @@ def test_emu_sequential_envelope_replay(oracle_det, tmp_path):
 
 
 def test_emu_varied_data_shapes(psd, oracle_det, tmp_path, monkeypatch):
-    gp.test_varied_data_shapes(psd, oracle_det, tmp_path, monkeypatch, 6, 7)
+    gp.test_varied_data_shapes(psd, oracle_det, tmp_path, monkeypatch, 4, 7)
 
 
 def test_emu_grid_properties_small(psd):
@@ -200,4 +200,4 @@ def test_emu_checkpointed_store_limits(psd, tmp_path, monkeypatch):
 
 
 def test_emu_mixed_launch(psd, tmp_path, monkeypatch):
-    gp2.test_mixed_launch_of_unequal_contigs(psd, tmp_path, monkeypatch, 900, 60, 63)
+    gp2.test_mixed_launch_of_unequal_contigs(psd, tmp_path, monkeypatch, 500, 40, 63)
