@@ -37,8 +37,12 @@ def main():
     from peaksegdisk_amd.grid import ProblemSet
     lib = _native.declare(ctypes.CDLL(lib_path))
     lib.peakseg_hip_problem_set_profile.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
-    cs, ce, cnt = synthetic.poisson_coverage(bins, seed=1)
-    pens = synthetic.penalty_grid(npen)
+    if os.environ.get("PSD_PROFILE_DATA") == "increasing": # config 5: long functions
+        cs, ce, cnt = synthetic.increasing_coverage(bins)
+        pens = [100.0] * npen
+    else:
+        cs, ce, cnt = synthetic.poisson_coverage(bins, seed=1)
+        pens = synthetic.penalty_grid(npen)
     pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, float(p)) for p in pens], lib=lib)
     f_ms, b_ms = pset.solve()
     print("bins=%d penalties=%d forward=%.1f ms backtrack=%.1f ms (stamped build)" % (
