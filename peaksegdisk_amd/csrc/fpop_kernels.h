@@ -585,6 +585,7 @@ PSD_D void forward_body(const DeviceArgs &a) {
 
   psd_tables_init(); /* exp/log tables -> LDS */
   if (threadIdx.x == 0) {
+    if (a.started) atomicAdd_system(a.started, 1);
     g_sm.abort_status[0] = g_sm.abort_status[1] = g_sm.abort_status[2] = 0;
     g_sm.abort_err[0] = g_sm.abort_err[1] = g_sm.abort_err[2] = 0;
     for (int i = 0; i < 6; i++) g_sm.n[i] = 0;

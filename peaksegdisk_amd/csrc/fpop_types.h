@@ -98,6 +98,9 @@ struct DeviceArgs {
   const long long *prob_ckpt_off; /* first checkpoint slot of each problem */
   double *ckpt_f64;
   int *ckpt_i32;
+  /* mixed launch: host-visible count of latency-build workgroups that have started (the host
+   * holds the packed part back until they all have their CUs); nullptr otherwise */
+  int *started;
 };
 
 }  // namespace psd

@@ -67,6 +67,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <thread>
 #include <string>
@@ -284,6 +285,7 @@ struct psd_problem_set {
   std::vector<int> order;  /* problems, longest contig first */
   hipStream_t stream2 = nullptr;
   hipEvent_t ev2 = nullptr;
+  int *started = nullptr; /* pinned host word: latency-build workgroups of a mixed launch */
   std::vector<void *> allocs;
   unsigned long long bytes = 0;
 };
@@ -448,6 +450,7 @@ extern "C" void peakseg_hip_problem_set_destroy(psd_problem_set *s) {
   if (s->ev2) (void)hipEventDestroy(s->ev2);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
+  if (s->started) (void)hipHostFree(s->started);
   delete s;
 }
 
@@ -695,6 +698,7 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
   }
 #endif
   if (e == hipSuccess) e = hipEventCreate(&s->ev2);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&s->started, sizeof(int), hipHostMallocDefault);
   for (auto &ev : s->ev)
     if (e == hipSuccess) e = hipEventCreate(&ev);
   if (e != hipSuccess) {
@@ -768,17 +772,33 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
       d_thr.n_problems = s->n_problems - L;
       d_thr.prob_order = s->d.prob_order + L;
       HIP_TRY(hipStreamWaitEvent(s->stream2, s->ev[0], 0));
-      if (s->ckpt_interval > 0) {
+      /* A latency-build workgroup needs every register of a CU: once the packed part has put
+       * a workgroup on each CU it would find none free before the packed part has drained,
+       * and the two kernels would run one after the other.  So its workgroups report in (one
+       * system-scope atomic each, on a pinned host word) and the packed part is launched when
+       * all of them have started -- or after two seconds, whatever they are waiting for. */
+      __atomic_store_n(s->started, 0, __ATOMIC_RELEASE);
+      d_lat.started = s->started;
+      if (s->ckpt_interval > 0)
         hipLaunchKernelGGL(psd::lat::fpop_forward_ckpt_kernel, dim3((unsigned)L),
                            dim3(psd::lat::FORWARD_THREADS), 0, s->stream2, d_lat);
-        hipLaunchKernelGGL(psd::thr::fpop_forward_ckpt_kernel, dim3((unsigned)d_thr.n_problems),
-                           dim3(psd::thr::FORWARD_THREADS), 0, s->stream, d_thr);
-      } else {
+      else
         hipLaunchKernelGGL(psd::lat::fpop_forward_kernel, dim3((unsigned)L),
                            dim3(psd::lat::FORWARD_THREADS), 0, s->stream2, d_lat);
+      HIP_TRY(hipGetLastError());
+      (void)hipStreamQuery(s->stream2); /* submit now */
+      {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (__atomic_load_n(s->started, __ATOMIC_ACQUIRE) < L &&
+               std::chrono::steady_clock::now() - t0 < std::chrono::seconds(2))
+          std::this_thread::yield();
+      }
+      if (s->ckpt_interval > 0)
+        hipLaunchKernelGGL(psd::thr::fpop_forward_ckpt_kernel, dim3((unsigned)d_thr.n_problems),
+                           dim3(psd::thr::FORWARD_THREADS), 0, s->stream, d_thr);
+      else
         hipLaunchKernelGGL(psd::thr::fpop_forward_kernel, dim3((unsigned)d_thr.n_problems),
                            dim3(psd::thr::FORWARD_THREADS), 0, s->stream, d_thr);
-      }
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(s->ev2, s->stream2));
       HIP_TRY(hipStreamWaitEvent(s->stream, s->ev2, 0));

@@ -248,6 +248,14 @@ hipError_t hipFree(void *p) {
   free(p);
   return hipSuccess;
 }
+hipError_t hipHostMalloc(void **p, size_t n, unsigned) {
+  *p = calloc(1, n ? n : 1);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipHostFree(void *p) {
+  free(p);
+  return hipSuccess;
+}
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind) {
   memcpy(dst, src, n);
   return hipSuccess;

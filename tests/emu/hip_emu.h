@@ -74,6 +74,7 @@ static inline int atomicAdd(int *p, int v) {
   *p = o + v;
   return o;
 }
+static inline int atomicAdd_system(int *p, int v) { return atomicAdd(p, v); }
 static inline int atomicMax(int *p, int v) {
   int o = *p;
   if (v > o) *p = v;
@@ -104,6 +105,9 @@ hipError_t hipSetDevice(int d);
 hipError_t hipGetDevice(int *d);
 hipError_t hipMalloc(void **p, size_t n);
 hipError_t hipFree(void *p);
+hipError_t hipHostMalloc(void **p, size_t n, unsigned flags);
+hipError_t hipHostFree(void *p);
+#define hipHostMallocDefault 0u
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t s);
 hipError_t hipMemset(void *p, int v, size_t n);
@@ -112,6 +116,7 @@ hipError_t hipStreamCreate(hipStream_t *s);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipStreamWaitEvent(hipStream_t s, struct emu_event *e, unsigned flags);
+static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 hipError_t hipDeviceSynchronize();
 hipError_t hipEventCreate(hipEvent_t *e);
 hipError_t hipEventDestroy(hipEvent_t e);

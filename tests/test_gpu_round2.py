@@ -462,7 +462,7 @@ def test_throughput_set_every_contig_vs_oracle(psd, tmp_path):
     problems = [(k, float(p)) for k in range(n_contigs) for p in pens]
     pset = ProblemSet(contigs, problems)
     pset.solve()
-    assert pset.kernel_build == "thr"
+    assert "thr" in pset.kernel_build  # "lat+thr" when the planner mixes
 
     def oracle_job(k):
         cs, ce, cnt = data[k]
