@@ -159,7 +159,7 @@ int peakseg_hip_problem_set_export_db(psd_problem_set *set, int problem, const i
 
 /* Which build of the forward kernel the last solve used: "lat" (latency build: helper waves,
  * one workgroup per CU; sets of at most one problem per CU), "thr" (throughput build:
- * 5 workgroups per CU) or "lat+thr" (a set that oversubscribes the chip with contigs of unequal
+ * 4 workgroups per CU) or "lat+thr" (a set that oversubscribes the chip with contigs of unequal
  * length: its longest problems on the latency build, the rest packed on the throughput build,
  * concurrently).  Same results either way; the environment variable
  * PEAKSEG_HIP_VARIANT=lat|thr overrides the choice. */

@@ -16,12 +16,13 @@
  *        operations inlined into the kernel's loop (4 waves per workgroup, all registers of
  *        the SIMDs: 1 workgroup per CU).  Fastest per problem; used while every problem of
  *        the set gets a CU of its own (the 64-penalty grid of one contig runs here).
- *   thr  throughput build: 56 pieces per LDS list, no helper waves, operations out of line,
- *        registers for 3 waves per SIMD (2 waves per workgroup, 30 KB of LDS: 5 workgroups per
- *        CU).  Slower per problem, five times the problems per CU; used for sets that
- *        oversubscribe the chip (many contigs x many penalties).  Measured against 64 pieces,
- *        2 waves per SIMD and 4 workgroups per CU: +7.5 % on 6144 problems
- *        (profiles/r02/ab_thr_occupancy.log).
+ *   thr  throughput build: 64 pieces per LDS list, no helper waves, operations out of line
+ *        (2 waves per workgroup, 4 workgroups per CU).  ~12% slower per problem, four times
+ *        the problems per CU; used for sets that oversubscribe the chip (many contigs x many
+ *        penalties).  (Registers for 3 waves per SIMD with 56-piece lists -- 5 workgroups per
+ *        CU, -DPSD_THR_LDS_CAP=56 -DPSD_THR_WAVES_PER_EU=3 -- gain 7.5 % on 6144 equal problems
+ *        and lose 7 % on the 24-contig x 64-penalty shape, whose end is set by its longest
+ *        problems: profiles/r02/ab_thr_occupancy.log.)
  * Both produce identical results. */
 #define PSD_VARIANT lat
 #define PSD_LDS_CAP 128
@@ -35,11 +36,11 @@
 #undef PSD_HELPER_WAVES
 #undef PSD_MATH_VK
 #define PSD_VARIANT thr
-#ifndef PSD_THR_LDS_CAP /* A/B builds: -DPSD_THR_LDS_CAP=64 -DPSD_THR_WAVES_PER_EU=2 */
-#define PSD_THR_LDS_CAP 56
+#ifndef PSD_THR_LDS_CAP /* A/B builds: -DPSD_THR_LDS_CAP=56 -DPSD_THR_WAVES_PER_EU=3 */
+#define PSD_THR_LDS_CAP 64
 #endif
 #ifndef PSD_THR_WAVES_PER_EU
-#define PSD_THR_WAVES_PER_EU 3
+#define PSD_THR_WAVES_PER_EU 2
 #endif
 #define PSD_LDS_CAP PSD_THR_LDS_CAP
 #define PSD_KERNEL_WAVES_PER_EU PSD_THR_WAVES_PER_EU
@@ -715,7 +716,7 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
                                              float *backtrack_ms) {
   HIP_TRY(hipSetDevice(s->device));
   /* the latency build wants a CU per problem: beyond that, problems would queue behind each
-   * other and the throughput build (5 per CU) finishes the set sooner.
+   * other and the throughput build (4 per CU) finishes the set sooner.
    * PEAKSEG_HIP_VARIANT=lat|thr overrides (tests, A/B runs). */
   s->throughput = s->n_problems > s->n_cu;
   bool forced = false;
@@ -724,14 +725,14 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
     if (!strcmp(e, "thr")) s->throughput = true, forced = true;
   }
   /* Mixed launch for sets of unequal contigs that oversubscribe the chip: a problem on the
-   * throughput build advances about 23 k data points per second, on the latency build (a CU of
+   * throughput build advances about 27 k data points per second, on the latency build (a CU of
    * its own) about 90 k, so the longest problems would decide when the set ends.  The L longest
    * problems go to the latency build -- launched first, on a stream of its own, one CU each --
-   * and the rest is packed five to a CU on what is left; L minimises the later of the two
+   * and the rest is packed four to a CU on what is left; L minimises the later of the two
    * predicted ends.  (Equal contigs: L = 0.) */
   s->n_lat_mixed = 0;
   if (s->throughput && !forced) {
-    const double lat_rate = 90e3, thr_rate = 23e3, thr_per_cu = 5.0;
+    const double lat_rate = 90e3, thr_rate = 27e3, thr_per_cu = 4.0;
     std::vector<double> len((size_t)s->n_problems);
     double rest = 0.0;
     for (int k = 0; k < s->n_problems; k++) {

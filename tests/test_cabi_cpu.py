@@ -211,9 +211,8 @@ def test_fast_parser_equals_sscanf(native, tmp_path):
 
 def test_kernel_resource_budgets(tmp_path):
     """The two builds of the forward kernel are defined by their occupancy:
-    the throughput build must fit 3 waves per SIMD and 5 workgroups per CU (<= 31 KB LDS: the
-    allocation granularity leaves no room at 32 KB) -- a register or LDS regression silently
-    costs a workgroup per CU -- and the latency build must
+    the throughput build must fit 2 waves per SIMD and 4 workgroups per CU (<= 40 KB LDS) --
+    a register or LDS regression silently halves its throughput -- and the latency build must
     fit one workgroup of 4 waves.  Checked on the compiler's resource remarks (no GPU needed)."""
     import re
     import subprocess
@@ -238,6 +237,6 @@ def test_kernel_resource_budgets(tmp_path):
                 info[name][key] = int(m.group(1))
     thr = next(v for k, v in info.items() if "3thr19fpop_forward_kernel" in k)
     lat = next(v for k, v in info.items() if "3lat19fpop_forward_kernel" in k)
-    assert thr["Occupancy [waves/SIMD]"] >= 3, thr
-    assert thr["LDS Size [bytes/block]"] <= 31 * 1024, thr
+    assert thr["Occupancy [waves/SIMD]"] >= 2, thr
+    assert thr["LDS Size [bytes/block]"] <= 40 * 1024, thr
     assert lat["Occupancy [waves/SIMD]"] >= 1 and lat["LDS Size [bytes/block]"] <= 160 * 1024, lat

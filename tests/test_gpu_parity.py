@@ -253,7 +253,7 @@ def test_adversarial_increasing_counts_spill(psd, oracle_det, tmp_path, n_bins):
 def test_throughput_build_identical(psd, oracle_det, tmp_path, monkeypatch, n_bins, n_contigs):
     """The library carries two builds of the forward kernel (peakseg_hip.cpp): "lat" (helper
     waves, 128 pieces per LDS list) for sets that fit the chip at 2 workgroups per CU, "thr"
-    (no helper waves, 56 pieces per LDS list, 5 workgroups per CU) beyond that.  Same results:
+    (no helper waves, 64 pieces per LDS list, 4 workgroups per CU) beyond that.  Same results:
     a set large enough to pick "thr" by itself is compared with the same set forced onto
     "lat", and one contig's stored functions with the oracle's db byte for byte."""
     from peaksegdisk_amd import ProblemSet, synthetic

@@ -17,11 +17,17 @@ from peaksegdisk_amd.grid import ProblemSet  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--bins", type=int, default=100000)
 ap.add_argument("--contigs", type=int, default=1)
+ap.add_argument("--unequal", action="store_true",
+                help="contig lengths log-uniform in [bins/100, bins] (the config-4 shape)")
 ap.add_argument("libs", nargs="+")
 args = ap.parse_args()
 contigs = []
+lens = [args.bins] * args.contigs
+if args.unequal:
+    lens = np.exp(np.random.default_rng(4).uniform(np.log(args.bins / 100), np.log(args.bins),
+                                                   args.contigs)).astype(int)
 for k in range(args.contigs):
-    cs, ce, cnt = synthetic.poisson_coverage(args.bins, seed=1 + k)
+    cs, ce, cnt = synthetic.poisson_coverage(int(lens[k]), seed=1 + k)
     contigs.append((cnt, (ce - cs).astype(np.int32)))
 pens = synthetic.penalty_grid(64)
 problems = [(k, float(p)) for k in range(args.contigs) for p in pens]
@@ -50,7 +56,7 @@ for name in args.libs:
     lib = bind(name)
     ps = ProblemSet(contigs, problems, lib=lib)
     ps.solve()
-    f = [ps.solve()[0] for _ in range(2)]
-    print(name, "forward ms", min(f), "=> bins/s", args.bins * len(problems) / (min(f) / 1e3),
-          flush=True)
+    f = [ps.solve()[0] for _ in range(1 if args.unequal else 2)]
+    print(name, getattr(ps, "kernel_build", ""), "forward ms", min(f), "=> bins/s",
+          int(np.sum(lens)) * len(pens) / (min(f) / 1e3), flush=True)
     ps.close()
