@@ -496,6 +496,30 @@ constexpr int FORWARD_THREADS = 128;
 PSD_D void block_sync(int) { __syncthreads(); }
 #endif
 
+/* The barrier at the end of every data point, between the two chain waves only.
+ * PSD_FLAG_BARRIER (latency build): each wave publishes the barrier's number in LDS and polls
+ * the other's -- no s_barrier, and the helper waves, which never touch the lists, stay out of
+ * it (waking them through their mailbox for every data point cost more than the data point's
+ * imbalance).  Returns false if the other wave never came (never expected: the caller
+ * aborts the problem).  Otherwise the workgroup barrier. */
+PSD_D bool step_sync(int chain, unsigned seq) {
+#ifdef PSD_FLAG_BARRIER
+  constexpr int SPIN_LIMIT = 1 << 26; /* seconds */
+  wave_sync();
+  if (lane_id() == 0) flag_store((int *)&g_sm.arrived[chain], (int)seq);
+  for (int spin = 0; spin < SPIN_LIMIT; spin++) {
+    /* lane 0's reading decides for the wave */
+    if (rdlane_i(flag_load((int *)&g_sm.arrived[1 - chain]), 0) - (int)seq >= 0) return true;
+    spin_pause();
+  }
+  return false;
+#else
+  (void)seq;
+  block_sync(chain);
+  return true;
+#endif
+}
+
 /* Take a slot of the HBM spill pool for this workgroup's problem (cold: at most once per
  * problem).  Both chain waves call it; returns the slot, or -1 when the pool is exhausted. */
 PSD_COLD_DEV int take_spill_slot(const DeviceArgs &a, int chain) {
@@ -590,6 +614,7 @@ PSD_D void forward_body(const DeviceArgs &a) {
     g_sm.abort_err[0] = g_sm.abort_err[1] = g_sm.abort_err[2] = 0;
     for (int i = 0; i < 6; i++) g_sm.n[i] = 0;
     g_sm.serial[0] = g_sm.serial[1] = 0;
+    g_sm.arrived[0] = g_sm.arrived[1] = 0xffffffffu;
 #ifdef PSD_PROFILE
     for (int i = 0; i < N_PROF; i++)
       g_sm.prof[0][i] = g_sm.prof[1][i] = g_sm.prof[2][i] = g_sm.prof[3][i] = 0;
@@ -729,7 +754,11 @@ PSD_D void forward_body(const DeviceArgs &a) {
         }
       }
       PSD_PROF_ADD(PROF_ARENA);
-      block_sync(chain);
+      if (!step_sync(chain, sync_no)) {
+        status = PST_REF_THROW;
+        if (lane == 0) g_sm.abort_err[slot] = WERR_HELPER;
+        break;
+      }
       PSD_PROF_ADD(PROF_BARRIER);
       status = uniform_i(g_sm.abort_status[slot]);
       /* three rotating slots: the one cleared here is first written two barriers later */

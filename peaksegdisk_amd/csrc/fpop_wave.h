@@ -84,6 +84,7 @@ struct Mail {
 struct SharedBlock {
   ListStore list[6];
   ScratchStore sc[2];
+  unsigned arrived[2]; /* number of the last end-of-data-point barrier the chain wave reached */
   int n[6];
   int abort_status[3];
   int abort_err[3];
@@ -417,26 +418,11 @@ PSD_D void piece_costs_wave(const L &in, int n, const S &s, LanePiece &P) {
   wave_sync();
 }
 
-/* ------------------------------------------------------------------------------------- */
-/* min-less: out(x) = min_{y<=x} in(y).  All output pieces get data_i = data_i_out (the
- * driver's set_prev_seg_end) and Constant += add_const (its add(0,0,penalty/cum_weight_prev),
- * PeakSegFPOPLog.cpp:290-296). */
-template <bool SMALL, class L, class S>
-PSD_D int min_less_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
-                        double add_const_) {
-  const L in = in_.uniformed(), out = out_.uniformed();
-  const S s = s_.uniformed();
-  const int n = uniform_i(n_), cap = uniform_i(cap_), data_i_out = uniform_i(data_i_out_);
-  const double add_const = uniform_d(add_const_);
+/* First pass of min-less: per piece the end costs and optimum (piece_costs_wave) and what the
+ * walk does with the piece when it reaches it in search mode. */
+template <class L, class S>
+PSD_D void min_less_pre(const L &in, int n, const S &s, LanePiece &P) {
   const int lane = lane_id();
-  /* lane i holds piece i; SMALL: the caller guarantees n <= WAVE (the other code drops out) */
-  if (SMALL) PSD_ASSUME(n <= WAVE);
-  const bool small = SMALL || n <= WAVE;
-  LanePiece P;
-  P.c.Linear = P.c.Log = P.c.Constant = 0.0;
-  P.mn = P.mx = P.lc = P.rc = P.om = P.mu = P.muc = P.oc2 = 0.0;
-  P.cls = CLS_STORE;
-  PSD_PROF_T0();
   piece_costs_wave(in, n, s, P);
   /* what the walk does with piece i when it reaches it in search mode */
   for (int base = 0; base < n; base += WAVE) {
@@ -474,6 +460,64 @@ PSD_D int min_less_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
     }
   }
   wave_sync();
+}
+
+/* First pass of min-more, as min_less_pre. */
+template <class L, class S>
+PSD_D void min_more_pre(const L &in, int n, const S &s, LanePiece &P) {
+  const int lane = lane_id();
+  piece_costs_wave(in, n, s, P);
+  for (int base = 0; base < n; base += WAVE) {
+    int i = base + lane;
+    if (i < n) {
+      int cls;
+      if (in.Log(i) == 0) { /* fpl:458-467 */
+        cls = CLS_STORE;
+      } else { /* fpl:468-548 */
+        double mu = s.mu(i), mu_cost = s.muc(i);
+        bool prev_ok = true;
+        if (i > 0) {
+          double prev_cost_right = s.rc(i - 1);
+          prev_ok = NEWTON_EPSILON < prev_cost_right - mu_cost;
+        }
+        double this_cost_left = s.lc(i);
+        if (in.mx(i) <= mu) {
+          double this_cost_diff = this_cost_left - s.rc(i);
+          cls = (NEWTON_EPSILON < this_cost_diff) ? CLS_CONST_EDGE : CLS_STORE;
+        } else if (in.mn(i) < mu && NEWTON_EPSILON < this_cost_left - mu_cost && prev_ok) {
+          cls = CLS_CONST_MU;
+        } else {
+          cls = CLS_STORE;
+        }
+      }
+      s.cls(i) = cls;
+      if (base == 0) P.cls = cls;
+    }
+  }
+  wave_sync();
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* min-less: out(x) = min_{y<=x} in(y).  All output pieces get data_i = data_i_out (the
+ * driver's set_prev_seg_end) and Constant += add_const (its add(0,0,penalty/cum_weight_prev),
+ * PeakSegFPOPLog.cpp:290-296). */
+template <bool SMALL, class L, class S>
+PSD_D int min_less_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
+                        double add_const_) {
+  const L in = in_.uniformed(), out = out_.uniformed();
+  const S s = s_.uniformed();
+  const int n = uniform_i(n_), cap = uniform_i(cap_), data_i_out = uniform_i(data_i_out_);
+  const double add_const = uniform_d(add_const_);
+  const int lane = lane_id();
+  /* lane i holds piece i; SMALL: the caller guarantees n <= WAVE (the other code drops out) */
+  if (SMALL) PSD_ASSUME(n <= WAVE);
+  const bool small = SMALL || n <= WAVE;
+  LanePiece P;
+  P.c.Linear = P.c.Log = P.c.Constant = 0.0;
+  P.mn = P.mx = P.lc = P.rc = P.om = P.mu = P.muc = P.oc2 = 0.0;
+  P.cls = CLS_STORE;
+  PSD_PROF_T0();
+  min_less_pre(in, n, s, P);
   PSD_PROF_ADD(PROF_PRE);
   /* uniform reads of piece j: registers of lane j when the function fits one wave */
   auto cls_at = [&](int j) -> int { return small ? rdlane_i(P.cls, j) : s.cls(j); };
@@ -767,35 +811,7 @@ PSD_D int min_more_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_) 
   P.mn = P.mx = P.lc = P.rc = P.om = P.mu = P.muc = P.oc2 = 0.0;
   P.cls = CLS_STORE;
   PSD_PROF_T0();
-  piece_costs_wave(in, n, s, P);
-  for (int base = 0; base < n; base += WAVE) {
-    int i = base + lane;
-    if (i < n) {
-      int cls;
-      if (in.Log(i) == 0) { /* fpl:458-467 */
-        cls = CLS_STORE;
-      } else { /* fpl:468-548 */
-        double mu = s.mu(i), mu_cost = s.muc(i);
-        bool prev_ok = true;
-        if (i > 0) {
-          double prev_cost_right = s.rc(i - 1);
-          prev_ok = NEWTON_EPSILON < prev_cost_right - mu_cost;
-        }
-        double this_cost_left = s.lc(i);
-        if (in.mx(i) <= mu) {
-          double this_cost_diff = this_cost_left - s.rc(i);
-          cls = (NEWTON_EPSILON < this_cost_diff) ? CLS_CONST_EDGE : CLS_STORE;
-        } else if (in.mn(i) < mu && NEWTON_EPSILON < this_cost_left - mu_cost && prev_ok) {
-          cls = CLS_CONST_MU;
-        } else {
-          cls = CLS_STORE;
-        }
-      }
-      s.cls(i) = cls;
-      if (base == 0) P.cls = cls;
-    }
-  }
-  wave_sync();
+  min_more_pre(in, n, s, P);
   PSD_PROF_ADD(PROF_PRE);
   auto cls_at = [&](int j) -> int { return small ? rdlane_i(P.cls, j) : s.cls(j); };
   auto mu_at = [&](int j) -> double { return small ? rdlane_d(P.mu, j) : s.mu(j); };
@@ -1644,7 +1660,7 @@ PSD_D void helper_loop(int chain) {
     }
     wave_sync();
     if (lane == 0) flag_store(&m.seq_done, seen);
-  }
+    }
 }
 #endif
 

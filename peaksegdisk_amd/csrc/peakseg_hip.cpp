@@ -30,10 +30,14 @@
 #ifndef PSD_NO_HELPER_WAVES /* -DPSD_NO_HELPER_WAVES: A/B builds (tools/ab_libs.py) */
 #define PSD_HELPER_WAVES 1
 #endif
+#ifndef PSD_NO_FLAG_BARRIER /* -DPSD_NO_FLAG_BARRIER: A/B builds */
+#define PSD_FLAG_BARRIER 1
+#endif
 #include "fpop_kernels.h"
 #undef PSD_VARIANT
 #undef PSD_LDS_CAP
 #undef PSD_HELPER_WAVES
+#undef PSD_FLAG_BARRIER
 #undef PSD_MATH_VK
 #define PSD_VARIANT thr
 #ifndef PSD_THR_LDS_CAP /* A/B builds: -DPSD_THR_LDS_CAP=56 -DPSD_THR_WAVES_PER_EU=3 */

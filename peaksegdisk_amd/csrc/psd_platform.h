@@ -112,6 +112,9 @@ PSD_D int flag_load(const int *p) {
 PSD_D void flag_store(int *p, int v) {
   __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+/* between two polls of a flag.  Measured on the latency build: polling without a pause takes
+ * LDS cycles from the waves at work (-1.2 %), and longer sleeps ended by s_wakeup from the
+ * posting wave are slower still (-2 % to -4 %): profiles/r02/ab_step_barrier.log */
 PSD_D void spin_pause() { __builtin_amdgcn_s_sleep(1); }
 /* make this thread's global stores visible to the other waves of the device */
 PSD_D void device_fence() { __threadfence(); }
