@@ -48,6 +48,9 @@
 #endif
 #define PSD_LDS_CAP PSD_THR_LDS_CAP
 #define PSD_KERNEL_WAVES_PER_EU PSD_THR_WAVES_PER_EU
+#ifdef PSD_THR_FLAG_BARRIER /* A/B: measured slower than the workgroup barrier */
+#define PSD_FLAG_BARRIER 1
+#endif
 #if !defined(PSD_CALL_LDS_OPS) && !defined(PSD_THR_INLINE_OPS) /* A/B: -DPSD_THR_INLINE_OPS */
 #define PSD_CALL_LDS_OPS 1
 #define PSD_CALL_LDS_OPS_THR_ONLY 1
