@@ -31,7 +31,7 @@ namespace PSD_VARIANT {
 /* lists / scratch of spill-pool slot p (a problem's slot, see take_spill_slot) */
 PSD_D GlobalList global_list(const DeviceArgs &a, int p, int id) {
   const size_t cap = (size_t)a.spill_cap;
-  double *f = a.spill_f64 + ((size_t)p * 48 + (size_t)id * 6) * cap;
+  gdouble *f = (gdouble *)(a.spill_f64 + ((size_t)p * 48 + (size_t)id * 6) * cap);
   GlobalList r;
   r.Lin_ = f;
   r.Log_ = f + cap;
@@ -39,13 +39,13 @@ PSD_D GlobalList global_list(const DeviceArgs &a, int p, int id) {
   r.mn_ = f + 3 * cap;
   r.mx_ = f + 4 * cap;
   r.prv_ = f + 5 * cap;
-  r.di_ = a.spill_i32 + ((size_t)p * 12 + (size_t)id) * cap;
+  r.di_ = (gint *)(a.spill_i32 + ((size_t)p * 12 + (size_t)id) * cap);
   return r;
 }
 PSD_D GlobalScratch global_scratch(const DeviceArgs &a, int p, int wave) {
   const size_t cap = (size_t)a.spill_cap;
-  double *f = a.spill_f64 + ((size_t)p * 48 + 36 + (size_t)wave * 6) * cap;
-  int *q = a.spill_i32 + ((size_t)p * 12 + 6) * cap;
+  gdouble *f = (gdouble *)(a.spill_f64 + ((size_t)p * 48 + 36 + (size_t)wave * 6) * cap);
+  gint *q = (gint *)(a.spill_i32 + ((size_t)p * 12 + 6) * cap);
   GlobalScratch r;
   r.lc_ = f;
   r.rc_ = f + cap;
@@ -110,12 +110,12 @@ PSD_D bool arena_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &f, i
   for (int base = 0; base < n; base += WAVE) {
     int i = base + lane;
     if (i < n) {
-      a.ar_mx[off + i] = f.mx(i);
-      a.ar_prv[off + i] = f.prv(i);
-      a.ar_di[off + i] = f.di(i);
+      ((gdouble *)a.ar_mx)[off + i] = f.mx(i);
+      ((gdouble *)a.ar_prv)[off + i] = f.prv(i);
+      ((gint *)a.ar_di)[off + i] = f.di(i);
     }
   }
-  if (lane == 0) a.fn_ref[fn_index] = (off << FN_COUNT_BITS) | (unsigned long long)n;
+  if (lane == 0) ((gull *)a.fn_ref)[fn_index] = (off << FN_COUNT_BITS) | (unsigned long long)n;
   cur.used += n;
   return true;
 }
@@ -158,14 +158,14 @@ PSD_D bool scale_add_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &
       f.Log(i) = lo * inv_cum_weight;
       f.Con(i) = co * inv_cum_weight;
       if (store) {
-        a.ar_mx[off + i] = mx;
-        a.ar_prv[off + i] = prv;
-        a.ar_di[off + i] = di;
+        ((gdouble *)a.ar_mx)[off + i] = mx; /* (in a called function `a` is in memory) */
+        ((gdouble *)a.ar_prv)[off + i] = prv;
+        ((gint *)a.ar_di)[off + i] = di;
       }
     }
   }
   if (store) {
-    if (lane == 0) a.fn_ref[fn_index] = (off << FN_COUNT_BITS) | (unsigned long long)n;
+    if (lane == 0) ((gull *)a.fn_ref)[fn_index] = (off << FN_COUNT_BITS) | (unsigned long long)n;
     cur.used += n;
   }
   return ok;
@@ -368,6 +368,14 @@ PSD_COLD_DEV int first_point(const DeviceArgs &a, ArenaCursor &cur, unsigned lon
   return arena_store_wave(a, cur, own_new, 1, fn0) ? 1 : -WERR_ARENA;
 }
 
+#ifndef PSD_HBM_HELPER /* A/B: -DPSD_HBM_HELPER=1 sends the spill path's larger roots to the helper waves */
+#define PSD_HBM_HELPER 0
+#endif
+#ifdef PSD_HELPER_WAVES
+constexpr bool HBM_HELP = PSD_HBM_HELPER != 0;
+#else
+constexpr bool HBM_HELP = false;
+#endif
 /* The same step with every list in the HBM spill area (functions that outgrew LDS): a cold,
  * out-of-line function, so that its addressing does not hold registers in the kernel's loop. */
 PSD_COLD_DEV int chain_step_hbm(const DeviceArgs &a, ArenaCursor &cur,
@@ -378,7 +386,7 @@ PSD_COLD_DEV int chain_step_hbm(const DeviceArgs &a, ArenaCursor &cur,
   p = uniform_i(p);
   chain = uniform_i(chain);
   t = uniform_i(t);
-  return chain_step<false>(a, cur, fn_index, chain, t,
+  return chain_step<HBM_HELP>(a, cur, fn_index, chain, t,
                            global_list(a, p, uniform_i(id_other_prev)), uniform_i(n_other),
                            global_list(a, p, uniform_i(id_own_prev)), uniform_i(n_own),
                            global_list(a, p, uniform_i(id_own_new)), global_list(a, p, 4 + chain),
@@ -496,6 +504,9 @@ constexpr int FORWARD_THREADS = 128;
 PSD_D void block_sync(int) { __syncthreads(); }
 #endif
 
+/* the workgroup barrier as a call (cold paths inside the kernel's loop) */
+PSD_COLD_DEV void block_sync_cold(int chain) { block_sync(uniform_i(chain)); }
+
 /* The barrier at the end of every data point, between the two chain waves only.
  * PSD_FLAG_BARRIER (latency build): each wave publishes the barrier's number in LDS and polls
  * the other's -- no s_barrier, and the helper waves, which never touch the lists, stay out of
@@ -539,7 +550,7 @@ PSD_COLD_DEV int take_spill_slot(const DeviceArgs &a, int chain) {
  * 2 + 2 cap ints {n_up, n_down, then per chain data_i}. */
 PSD_D GlobalList ckpt_list(const DeviceArgs &a, long long slot, int chain) {
   const size_t cap = (size_t)a.ckpt_cap;
-  double *f = a.ckpt_f64 + (size_t)slot * (2 + 12 * cap) + 2 + (size_t)chain * 6 * cap;
+  gdouble *f = (gdouble *)(a.ckpt_f64 + (size_t)slot * (2 + 12 * cap) + 2 + (size_t)chain * 6 * cap);
   GlobalList r;
   r.Lin_ = f;
   r.Log_ = f + cap;
@@ -547,7 +558,7 @@ PSD_D GlobalList ckpt_list(const DeviceArgs &a, long long slot, int chain) {
   r.mn_ = f + 3 * cap;
   r.mx_ = f + 4 * cap;
   r.prv_ = f + 5 * cap;
-  r.di_ = a.ckpt_i32 + (size_t)slot * (2 + 2 * cap) + 2 + (size_t)chain * cap;
+  r.di_ = (gint *)(a.ckpt_i32 + (size_t)slot * (2 + 2 * cap) + 2 + (size_t)chain * cap);
   return r;
 }
 /* this chain's function (LDS list `id`, n pieces) and the cumulated weight -> slot k */
@@ -740,6 +751,12 @@ PSD_D void forward_body(const DeviceArgs &a) {
                                penalty / cum_weight_prev_i, cum_weight_prev_i, w, coverage,
                                cum_weight_new));
         cur = cur_hbm;
+        /* With the lists in HBM the two waves first meet at the workgroup barrier, so that the
+         * flag barrier below finds the other wave there already: a wave that polls while the
+         * other one works through lists in HBM costs half as much again per data point
+         * (config 5, 1e5 data points: 7.6 s -> 11.4 s; profiles/r02/ab_step_barrier.log).
+         * in_hbm is the same in both waves. */
+        block_sync_cold(chain);
       }
       /* ---- end of pass: report, store the backtrack record, meet the other wave ---- */
       PSD_PROF_T0();

@@ -241,15 +241,15 @@ struct LdsScratch {
  * pieces (adversarial data, vignettes/Worst_case.Rmd).  `cap` pieces per list. */
 struct GlobalList {
   static constexpr bool in_lds = false;
-  double *Lin_, *Log_, *Con_, *mn_, *mx_, *prv_;
-  int *di_;
-  PSD_M double &Lin(int i) const { return Lin_[i]; }
-  PSD_M double &Log(int i) const { return Log_[i]; }
-  PSD_M double &Con(int i) const { return Con_[i]; }
-  PSD_M double &mn(int i) const { return mn_[i]; }
-  PSD_M double &mx(int i) const { return mx_[i]; }
-  PSD_M double &prv(int i) const { return prv_[i]; }
-  PSD_M int &di(int i) const { return di_[i]; }
+  gdouble *Lin_, *Log_, *Con_, *mn_, *mx_, *prv_;
+  gint *di_;
+  PSD_M gdouble &Lin(int i) const { return Lin_[i]; }
+  PSD_M gdouble &Log(int i) const { return Log_[i]; }
+  PSD_M gdouble &Con(int i) const { return Con_[i]; }
+  PSD_M gdouble &mn(int i) const { return mn_[i]; }
+  PSD_M gdouble &mx(int i) const { return mx_[i]; }
+  PSD_M gdouble &prv(int i) const { return prv_[i]; }
+  PSD_M gint &di(int i) const { return di_[i]; }
   PSD_M GlobalList shifted(int d) const {
     GlobalList r;
     r.Lin_ = Lin_ + d;
@@ -274,17 +274,17 @@ struct GlobalList {
   }
 };
 struct GlobalScratch {
-  double *lc_, *rc_, *om_, *mu_, *muc_, *oc2_;
-  int *cls_, *iv_;
+  gdouble *lc_, *rc_, *om_, *mu_, *muc_, *oc2_;
+  gint *cls_, *iv_;
   int iv_cap_;
-  PSD_M double &lc(int i) const { return lc_[i]; }
-  PSD_M double &rc(int i) const { return rc_[i]; }
-  PSD_M double &om(int i) const { return om_[i]; }
-  PSD_M double &mu(int i) const { return mu_[i]; }
-  PSD_M double &muc(int i) const { return muc_[i]; }
-  PSD_M double &oc2(int i) const { return oc2_[i]; }
-  PSD_M int &cls(int i) const { return cls_[i]; }
-  PSD_M int &iv(int i) const { return iv_[i]; }
+  PSD_M gdouble &lc(int i) const { return lc_[i]; }
+  PSD_M gdouble &rc(int i) const { return rc_[i]; }
+  PSD_M gdouble &om(int i) const { return om_[i]; }
+  PSD_M gdouble &mu(int i) const { return mu_[i]; }
+  PSD_M gdouble &muc(int i) const { return muc_[i]; }
+  PSD_M gdouble &oc2(int i) const { return oc2_[i]; }
+  PSD_M gint &cls(int i) const { return cls_[i]; }
+  PSD_M gint &iv(int i) const { return iv_[i]; }
   PSD_M int iv_cap() const { return iv_cap_; }
   PSD_M GlobalScratch uniformed() const {
     GlobalScratch r;

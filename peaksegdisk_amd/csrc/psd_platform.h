@@ -32,6 +32,20 @@
 #define PSD_COLD_DEV __device__ __attribute__((noinline, cold))
 #endif
 
+/* Data in HBM reached through pointers that a device function loads from memory: without
+ * the address space in the type the compiler must emit FLAT instructions, which are issued
+ * to the LDS and the vector-memory pipelines both -- slower, and slowed further by any wave
+ * that polls an LDS flag meanwhile. */
+#ifdef PSD_EMU
+typedef double gdouble;
+typedef int gint;
+typedef unsigned long long gull;
+#else
+typedef double __attribute__((address_space(1))) gdouble;
+typedef int __attribute__((address_space(1))) gint;
+typedef unsigned long long __attribute__((address_space(1))) gull;
+#endif
+
 #if defined(__clang__)
 #define PSD_ASSUME(x) __builtin_assume(x)
 #else
