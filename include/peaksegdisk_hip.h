@@ -98,6 +98,19 @@ int PeakSegFPOP_sequential_search(const char *problem_dir, int peaks_int, int ve
                                   int row_capacity, psd_search_row *rows, int *n_rows,
                                   int *chosen_row);
 
+/* The same search over several problem directories at once (additive: the reference runs one
+ * R process per directory, /root/reference/R/sequentialSearch_dir.R:34-38 with a `future`
+ * plan).  Every directory follows its own search -- the penalties, files and rows are those
+ * of PeakSegFPOP_sequential_search on that directory alone -- but the models the searches ask
+ * for in the same iteration are computed in one launch (PeakSegFPOP_dir_batch), so a set of
+ * contigs is searched in about the time of its longest search.  rows: n_dirs x row_capacity
+ * (directory d at rows + d*row_capacity); n_rows, chosen_row, status_out: one per directory
+ * (a directory whose search fails keeps its status and the others go on).  Returns the first
+ * non-zero status. */
+int PeakSegFPOP_sequential_search_batch(int n_dirs, char **problem_dirs, const int *peaks_int,
+                                        int verbose, int row_capacity, psd_search_row *rows,
+                                        int *n_rows, int *chosen_row, int *status_out);
+
 /* The text the reference's glue passes to Rf_error for a status
  * (/root/reference/src/interface.cpp:16-55); returns buf; empty string for status 0. */
 char *PeakSegFPOP_status_message(int status, const char *bedGraph, const char *penalty,

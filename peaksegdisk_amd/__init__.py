@@ -7,10 +7,11 @@ behind the reference's own entry points.  See DESIGN.md and INTEGRATION.md.
 from . import _native  # noqa: F401  (fails loudly when the HIP library is not built)
 from .api import (PeakSegError, PeakSegFPOP_dir, PeakSegFPOP_df, PeakSegFPOP_file,  # noqa: F401
                   PeakSegFPOP_vec, PeakSegFPOP_dir_batch, col_name_list, paste,
-                  sequentialSearch_dir, writeBedGraph)
+                  sequentialSearch_dir, sequentialSearch_dir_batch, writeBedGraph)
 from .grid import ProblemSet  # noqa: F401
 
 __all__ = ["PeakSegFPOP_file", "PeakSegFPOP_dir", "PeakSegFPOP_df", "PeakSegFPOP_vec",
-           "PeakSegFPOP_dir_batch", "sequentialSearch_dir", "writeBedGraph", "col_name_list", "paste",
+           "PeakSegFPOP_dir_batch", "sequentialSearch_dir", "sequentialSearch_dir_batch",
+           "writeBedGraph", "col_name_list", "paste",
            "ProblemSet",
            "PeakSegError"]

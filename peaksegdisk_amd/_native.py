@@ -106,6 +106,10 @@ def declare(lib):
         c.c_char_p, c.c_int, c.c_int, c.c_int, c.POINTER(PsdSearchRow), c.POINTER(c.c_int),
         c.POINTER(c.c_int)]
     lib.PeakSegFPOP_sequential_search.restype = c.c_int
+    lib.PeakSegFPOP_sequential_search_batch.argtypes = [
+        c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_int), c.c_int, c.c_int,
+        c.POINTER(PsdSearchRow), c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)]
+    lib.PeakSegFPOP_sequential_search_batch.restype = c.c_int
     lib.peakseg_hip_problem_set_set_penalty.argtypes = [c.c_void_p, c.c_int, c.c_double]
     lib.peakseg_hip_problem_set_set_penalty.restype = c.c_int
     lib.peakseg_hip_problem_set_arena_bytes_used.argtypes = [c.c_void_p]
@@ -126,6 +130,7 @@ EXPORTED_SYMBOLS = [
     "peakseg_hip_problem_set_destroy", "peakseg_hip_math_probe", "peakseg_hip_parse_probe",
     "peakseg_hip_problem_set_profile", "peakseg_hip_problem_set_kernel_build",
     "PeakSegFPOP_dir_batch", "PeakSegFPOP_sequential_search",
+    "PeakSegFPOP_sequential_search_batch",
     "peakseg_hip_problem_set_set_penalty", "peakseg_hip_problem_set_arena_bytes_used",
     "peakseg_hip_paste_double", "peakseg_hip_problem_set_checkpoint_interval",
 ]

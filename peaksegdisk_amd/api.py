@@ -366,16 +366,63 @@ def sequentialSearch_dir(problem_dir, peaks_int, verbose=0):
         if st >= _native.ERROR_NO_HIP_DEVICE and detail:
             msg = "%s (%s)" % (msg, detail)
         raise PeakSegError(st, msg)
+    return _search_result(problem_dir, [rows[k] for k in range(n_rows.value)], chosen.value)
+
+
+def _search_result(problem_dir, rows, chosen):
+    """sequentialSearch_dir's value from the rows of a native search: the chosen model with
+    $others (R/sequentialSearch_dir.R:96-102)."""
     model_list = {}
-    for k in range(n_rows.value):
-        r = rows[k]
+    for r in rows:
         pen_str = r.penalty_str.decode()
         L = PeakSegFPOP_dir(problem_dir, pen_str)  # the files of this model (cache hit)
         L.loss["iteration"] = r.iteration
         L.loss["under"] = np.nan if r.under_peaks == _native.SEARCH_NA else r.under_peaks
         L.loss["over"] = np.nan if r.over_peaks == _native.SEARCH_NA else r.over_peaks
         model_list[pen_str] = L
-    out = model_list[rows[chosen.value].penalty_str.decode()]
+    out = model_list[rows[chosen].penalty_str.decode()]
     others = pd.concat([m.loss for m in model_list.values()], ignore_index=True)
     out.others = others.sort_values("iteration", kind="stable").reset_index(drop=True)
+    return out
+
+
+def sequentialSearch_dir_batch(problem_dirs, peaks_int, verbose=0):
+    """sequentialSearch_dir over several problem directories at once (additive): each directory
+    gets the result sequentialSearch_dir(dir, peaks) gives, but the models the searches ask for
+    in the same iteration are computed in one device launch
+    (PeakSegFPOP_sequential_search_batch).  peaks_int: one target for all, or one per
+    directory.  Returns the list of results; a failed search raises for the first failure."""
+    import ctypes
+    problem_dirs = list(problem_dirs)
+    n = len(problem_dirs)
+    if isinstance(peaks_int, (int, np.integer)) and not isinstance(peaks_int, bool):
+        peaks_int = [int(peaks_int)] * n
+    peaks_int = [int(p) for p in peaks_int]
+    if len(peaks_int) != n or any(p < 0 for p in peaks_int):
+        raise ValueError("peaks.int: one non-negative integer, or one per problem directory")
+    if not all(isinstance(d, str) for d in problem_dirs):
+        raise ValueError("is.character(problem.dir) is not TRUE")
+    if n == 0:
+        return []
+    cap = 256
+    rows = (_native.PsdSearchRow * (cap * n))()
+    dirs = (ctypes.c_char_p * n)(*[os.fsencode(d) for d in problem_dirs])
+    peaks = (ctypes.c_int * n)(*peaks_int)
+    n_rows = (ctypes.c_int * n)()
+    chosen = (ctypes.c_int * n)()
+    status = (ctypes.c_int * n)()
+    _native.lib.PeakSegFPOP_sequential_search_batch(n, dirs, peaks, int(bool(verbose)), cap, rows,
+                                                    n_rows, chosen, status)
+    out = []
+    for d in range(n):
+        if status[d] == _native.ERROR_SEARCH_TOO_MANY_PEAKS:
+            raise ValueError(_native.last_error())
+        if status[d] != 0:
+            bg = os.path.realpath(os.path.join(problem_dirs[d], "coverage.bedGraph"))
+            k = n_rows[d]
+            pen = rows[d * cap + k].penalty_str.decode() if k < cap else ""
+            raise PeakSegError(status[d], _native.status_message(
+                status[d], bg, pen, "%s_penalty=%s.db" % (bg, pen)))
+        out.append(_search_result(problem_dirs[d],
+                                  [rows[d * cap + k] for k in range(n_rows[d])], chosen[d]))
     return out

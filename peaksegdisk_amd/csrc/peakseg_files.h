@@ -637,65 +637,52 @@ extern "C" int PeakSegFPOP_dir_batch(int n_problems, char **problem_dirs, char *
   return first;
 }
 
-extern "C" int PeakSegFPOP_sequential_search(const char *problem_dir, int peaks_int, int verbose,
-                                             int row_capacity, psd_search_row *rows, int *n_rows,
-                                             int *chosen_row) {
-  if (n_rows) *n_rows = 0;
-  if (chosen_row) *chosen_row = -1;
-  if (!problem_dir || peaks_int < 0 || !rows || row_capacity < 2) {
-    set_error("sequential search: bad arguments");
-    return ERROR_SEARCH_ARGUMENTS;
-  }
-  ResidentDir rd;
-  rd.dir = problem_dir;
-  rd.bedGraph = rd.dir + "/coverage.bedGraph";
-  rd.norm = real_path(rd.bedGraph);
-  const int NA = INT_MIN;
-  int n = 0;
-  int under = -1, over = -1, candidate = -1; /* row indices */
+namespace {
+
+/* The decisions of sequentialSearch_dir (R/sequentialSearch_dir.R:39-99) for one problem
+ * directory, apart from how a model is computed: the single-directory entry computes its models
+ * one after the other on a resident contig, the batch entry computes the pending model of every
+ * directory in one device launch.  Same state machine, so the same sequence of penalties. */
+struct SearchState {
+  int peaks_int = 0, row_capacity = 0;
+  psd_search_row *rows = nullptr;
+  int n = 0, under = -1, over = -1, candidate = -1, iteration = 0, first_new = 0;
+  int status = 0;
   std::vector<double> next_pen = {0.0, INFINITY};
-  int iteration = 0;
-  while (!next_pen.empty()) {
-    if (verbose) {
-      std::string line = "Next =";
-      for (size_t k = 0; k < next_pen.size(); k++)
-        line += (k ? ", " : " ") + r_paste_double(next_pen[k]);
-      emit_text("%s \n", line.c_str());
-    }
+
+  bool active() const { return status == 0 && !next_pen.empty(); }
+  void begin_iteration() {
     iteration++;
-    const int first_new = n;
-    for (double pen : next_pen) {
-      if (n >= row_capacity) {
-        set_error("sequential search: more than %d models", row_capacity);
-        return ERROR_SEARCH_ARGUMENTS;
-      }
-      psd_search_row &r = rows[n];
-      memset(&r, 0, sizeof r);
-      const std::string pen_str = r_paste_double(pen);
-      snprintf(r.penalty_str, sizeof r.penalty_str, "%s", pen_str.c_str());
-      LossRow lr;
-      bool cached = false;
-      int st = rd.model(r.penalty_str, lr, cached);
-      if (st) {
-        if (n_rows) *n_rows = n;
-        return st;
-      }
-      r.iteration = iteration;
-      r.under_peaks = under < 0 ? NA : rows[under].peaks;
-      r.over_peaks = over < 0 ? NA : rows[over].peaks;
-      r.penalty = lr.penalty;
-      r.peaks = (int)lr.peaks;
-      r.segments = (int)lr.segments;
-      r.bases = (int)lr.bases;
-      r.total_loss = lr.total_loss;
-      r.cached = cached ? 1 : 0;
-      n++;
-      if (getenv("PEAKSEG_HIP_TIMING")) /* progress of a long search (stderr is unbuffered) */
-        fprintf(stderr, "peakseg_hip timing: search model %d: penalty=%s peaks=%d%s, %.1f s so far "
-                        "in the kernel\n", n, r.penalty_str, r.peaks, cached ? " (cached)" : "",
-                rd.kernel_s);
+    first_new = n;
+  }
+  /* the next row, its penalty string filled in; nullptr when the table is full */
+  psd_search_row *new_row(double pen) {
+    if (n >= row_capacity) {
+      set_error("sequential search: more than %d models", row_capacity);
+      status = ERROR_SEARCH_ARGUMENTS;
+      return nullptr;
     }
-    if (n_rows) *n_rows = n;
+    psd_search_row &r = rows[n];
+    memset(&r, 0, sizeof r);
+    const std::string pen_str = r_paste_double(pen);
+    snprintf(r.penalty_str, sizeof r.penalty_str, "%s", pen_str.c_str());
+    return &r;
+  }
+  void record(psd_search_row &r, const LossRow &lr, bool cached) {
+    const int NA = INT_MIN;
+    r.iteration = iteration;
+    r.under_peaks = under < 0 ? NA : rows[under].peaks;
+    r.over_peaks = over < 0 ? NA : rows[over].peaks;
+    r.penalty = lr.penalty;
+    r.peaks = (int)lr.peaks;
+    r.segments = (int)lr.segments;
+    r.bases = (int)lr.bases;
+    r.total_loss = lr.total_loss;
+    r.cached = cached ? 1 : 0;
+    n++;
+  }
+  /* after the models of this iteration: the new bracket and the next penalty */
+  void end_iteration() {
     if (iteration == 1) {
       over = first_new;      /* penalty 0 */
       under = first_new + 1; /* penalty Inf */
@@ -703,7 +690,8 @@ extern "C" int PeakSegFPOP_sequential_search(const char *problem_dir, int peaks_
       if (max_peaks < peaks_int) {
         set_error("peaks.int=%d but max=%d peaks for N=%d data", peaks_int, max_peaks,
                   rows[over].bases);
-        return ERROR_SEARCH_TOO_MANY_PEAKS;
+        status = ERROR_SEARCH_TOO_MANY_PEAKS;
+        return;
       }
     } else {
       const int m = first_new;
@@ -735,11 +723,178 @@ extern "C" int PeakSegFPOP_sequential_search(const char *problem_dir, int peaks_
       }
     }
   }
-  if (chosen_row) *chosen_row = candidate;
+};
+
+void search_say_next(const std::vector<double> &next_pen) {
+  std::string line = "Next =";
+  for (size_t k = 0; k < next_pen.size(); k++)
+    line += (k ? ", " : " ") + r_paste_double(next_pen[k]);
+  emit_text("%s \n", line.c_str());
+}
+
+}  // namespace
+
+extern "C" int PeakSegFPOP_sequential_search(const char *problem_dir, int peaks_int, int verbose,
+                                             int row_capacity, psd_search_row *rows, int *n_rows,
+                                             int *chosen_row) {
+  if (n_rows) *n_rows = 0;
+  if (chosen_row) *chosen_row = -1;
+  if (!problem_dir || peaks_int < 0 || !rows || row_capacity < 2) {
+    set_error("sequential search: bad arguments");
+    return ERROR_SEARCH_ARGUMENTS;
+  }
+  ResidentDir rd;
+  rd.dir = problem_dir;
+  rd.bedGraph = rd.dir + "/coverage.bedGraph";
+  rd.norm = real_path(rd.bedGraph);
+  SearchState ss;
+  ss.peaks_int = peaks_int;
+  ss.row_capacity = row_capacity;
+  ss.rows = rows;
+  while (ss.active()) {
+    if (verbose) search_say_next(ss.next_pen);
+    ss.begin_iteration();
+    const std::vector<double> pens = ss.next_pen;
+    for (double pen : pens) {
+      psd_search_row *r = ss.new_row(pen);
+      if (!r) return ss.status;
+      LossRow lr;
+      bool cached = false;
+      int st = rd.model(r->penalty_str, lr, cached);
+      if (st) {
+        if (n_rows) *n_rows = ss.n;
+        return st;
+      }
+      ss.record(*r, lr, cached);
+      if (getenv("PEAKSEG_HIP_TIMING")) /* progress of a long search (stderr is unbuffered) */
+        fprintf(stderr, "peakseg_hip timing: search model %d: penalty=%s peaks=%d%s, %.1f s so far "
+                        "in the kernel\n", ss.n, r->penalty_str, r->peaks, cached ? " (cached)" : "",
+                rd.kernel_s);
+    }
+    if (n_rows) *n_rows = ss.n;
+    ss.end_iteration();
+    if (ss.status) return ss.status;
+  }
+  if (chosen_row) *chosen_row = ss.candidate;
   if (getenv("PEAKSEG_HIP_TIMING"))
     fprintf(stderr, "peakseg_hip timing: sequential search: %d models, %d dynamic programs, "
-                    "%.3f s in the kernel\n", n, rd.solves, rd.kernel_s);
+                    "%.3f s in the kernel\n", ss.n, rd.solves, rd.kernel_s);
   return 0;
+}
+
+/* sequentialSearch_dir over several problem directories at once (additive entry): every
+ * directory follows its own search, exactly as PeakSegFPOP_sequential_search would, but the
+ * models the searches ask for in the same iteration are computed in ONE launch
+ * (PeakSegFPOP_dir_batch: one problem per directory, the chip shared between them).  One
+ * search keeps four wave slots of 8192 busy; a genome's worth of contigs searched together
+ * costs about what its longest search costs.  rows: n_dirs x row_capacity; n_rows, chosen_row,
+ * status_out: per directory.  Returns the first non-zero status (0: every search ended). */
+extern "C" int PeakSegFPOP_sequential_search_batch(int n_dirs, char **problem_dirs,
+                                                   const int *peaks_int, int verbose,
+                                                   int row_capacity, psd_search_row *rows,
+                                                   int *n_rows, int *chosen_row,
+                                                   int *status_out) {
+  if (n_dirs <= 0) return 0;
+  if (!problem_dirs || !peaks_int || !rows || row_capacity < 2) {
+    set_error("sequential search: bad arguments");
+    return ERROR_SEARCH_ARGUMENTS;
+  }
+  std::vector<SearchState> ss((size_t)n_dirs);
+  std::vector<std::string> bedGraph((size_t)n_dirs);
+  for (int d = 0; d < n_dirs; d++) {
+    ss[(size_t)d].peaks_int = peaks_int[d];
+    ss[(size_t)d].row_capacity = row_capacity;
+    ss[(size_t)d].rows = rows + (size_t)d * (size_t)row_capacity;
+    if (peaks_int[d] < 0 || !problem_dirs[d]) ss[(size_t)d].status = ERROR_SEARCH_ARGUMENTS;
+    if (problem_dirs[d]) bedGraph[(size_t)d] = std::string(problem_dirs[d]) + "/coverage.bedGraph";
+    if (n_rows) n_rows[d] = 0;
+    if (chosen_row) chosen_row[d] = -1;
+  }
+  const double t0 = wall_now();
+  int round = 0, launches = 0;
+  for (;;) {
+    /* the models wanted now: (directory, row) pairs; a directory's first iteration asks for
+     * two (penalties 0 and Inf), later ones for one */
+    std::vector<int> who;
+    std::vector<psd_search_row *> row_of;
+    for (int d = 0; d < n_dirs; d++) {
+      SearchState &s = ss[(size_t)d];
+      if (!s.active()) continue;
+      if (verbose) {
+        emit_text("%s: ", problem_dirs[d]);
+        search_say_next(s.next_pen);
+      }
+      s.begin_iteration();
+      const std::vector<double> pens = s.next_pen;
+      for (double pen : pens) {
+        psd_search_row *r = s.new_row(pen);
+        if (!r) break;
+        who.push_back(d);
+        row_of.push_back(r);
+        s.n++; /* reserved; filled in below */
+      }
+      if (s.status) continue;
+      s.n = s.first_new; /* record() counts them again */
+    }
+    if (who.empty()) break;
+    round++;
+    /* drop the models of directories that have just failed */
+    std::vector<char *> dirs, pens;
+    std::vector<size_t> slot;
+    for (size_t k = 0; k < who.size(); k++) {
+      if (ss[(size_t)who[k]].status) continue;
+      dirs.push_back(problem_dirs[who[k]]);
+      pens.push_back(row_of[k]->penalty_str);
+      slot.push_back(k);
+    }
+    std::vector<int> st(dirs.size(), 0), cached(dirs.size(), 0);
+    if (!dirs.empty()) {
+      PeakSegFPOP_dir_batch((int)dirs.size(), dirs.data(), pens.data(), st.data(), cached.data());
+      launches++;
+    }
+    for (size_t j = 0; j < slot.size(); j++) {
+      const size_t k = slot[j];
+      const int d = who[k];
+      SearchState &s = ss[(size_t)d];
+      if (s.status) continue;
+      if (st[j]) {
+        s.status = st[j];
+        continue;
+      }
+      LossRow lr;
+      const std::string pre = bedGraph[(size_t)d] + "_penalty=" + row_of[k]->penalty_str;
+      if (!dir_cache_ok(bedGraph[(size_t)d], pre, lr)) {
+        set_error("sequential search: result files of %s are not consistent", pre.c_str());
+        s.status = ERROR_DEVICE_SOLVER;
+        continue;
+      }
+      s.record(*row_of[k], lr, cached[j] != 0);
+    }
+    for (int d = 0; d < n_dirs; d++) {
+      SearchState &s = ss[(size_t)d];
+      if (s.status || s.n == s.first_new || s.iteration == 0) continue;
+      bool mine = false;
+      for (size_t k = 0; k < who.size(); k++) mine = mine || who[k] == d;
+      if (!mine) continue;
+      if (n_rows) n_rows[d] = s.n;
+      s.end_iteration();
+    }
+    if (getenv("PEAKSEG_HIP_TIMING"))
+      fprintf(stderr, "peakseg_hip timing: search batch round %d: %zu models, %.1f s so far\n",
+              round, dirs.size(), wall_now() - t0);
+  }
+  int first = 0;
+  for (int d = 0; d < n_dirs; d++) {
+    const SearchState &s = ss[(size_t)d];
+    if (n_rows) n_rows[d] = s.n;
+    if (chosen_row) chosen_row[d] = s.status ? -1 : s.candidate;
+    if (status_out) status_out[d] = s.status;
+    if (s.status && !first) first = s.status;
+  }
+  if (getenv("PEAKSEG_HIP_TIMING"))
+    fprintf(stderr, "peakseg_hip timing: sequential search batch: %d directories, %d rounds, "
+                    "%d launches, %.3f s\n", n_dirs, round, launches, wall_now() - t0);
+  return first;
 }
 
 /* Tests: R's paste() of a double as this library formats penalties and timing files. */

@@ -46,3 +46,37 @@ sequentialSearch_dir_resident <- function
   out$others <- do.call(rbind, lapply(model.list, "[[", "loss"))[order(iteration)]
   out
 }
+
+sequentialSearch_dir_batch <- function
+### sequentialSearch_dir on several problem directories at once: every directory gets the
+### result sequentialSearch_dir(problem.dir, peaks.int) gives, but the models the searches ask
+### for in the same iteration are computed in one launch on the GPU.
+(problem.dir.vec, peaks.int.vec, verbose=0){
+  stopifnot(is.character(problem.dir.vec), is.integer(peaks.int.vec), all(0 <= peaks.int.vec))
+  n <- length(problem.dir.vec)
+  peaks.int.vec <- rep(peaks.int.vec, l=n)
+  capacity <- 256L
+  res <- .C(
+    "PeakSegFPOP_search_batch_interface",
+    problem.dir.vec, as.integer(n), peaks.int.vec, as.integer(verbose), capacity,
+    penalty=rep(strrep(" ", 39), capacity*n), iteration=integer(capacity*n),
+    under=integer(capacity*n), over=integer(capacity*n),
+    n.models=integer(n), chosen=integer(n), status=integer(n),
+    PACKAGE="PeakSegDisk")
+  if(any(res$status != 0)){
+    stop("error code ", res$status[res$status != 0][1])
+  }
+  lapply(seq_len(n), function(d){
+    i.vec <- (d-1L)*capacity + seq_len(res$n.models[d])
+    model.list <- lapply(i.vec, function(i){
+      L <- PeakSegFPOP_dir(problem.dir.vec[d], res$penalty[i])
+      L$loss$iteration <- res$iteration[i]
+      L$loss$under <- res$under[i]
+      L$loss$over <- res$over[i]
+      L
+    })
+    out <- model.list[[res$chosen[d]]]
+    out$others <- do.call(rbind, lapply(model.list, "[[", "loss"))[order(iteration)]
+    out
+  })
+}

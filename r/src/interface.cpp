@@ -81,11 +81,42 @@ void PeakSegFPOP_search_interface(char **dir, int *peaks_int, int *verbose, int 
   *chosen_out = chosen + 1; /* 1-based for R */
 }
 
+/* .C("PeakSegFPOP_search_batch_interface", problem.dir.vec, n, peaks.int.vec, verbose, capacity,
+ *    penalty=character(n*capacity), iteration=, under=, over=integer(n*capacity),
+ *    n.models=integer(n), chosen=integer(n), status=integer(n)): sequentialSearch_dir on every
+ * directory, the models of one iteration in one launch; directory d's rows are
+ * [d*capacity, d*capacity + n.models[d]). */
+void PeakSegFPOP_search_batch_interface(char **dirs, int *n_dirs, int *peaks_int, int *verbose,
+                                        int *capacity, char **penalty_out, int *iteration_out,
+                                        int *under_out, int *over_out, int *n_out,
+                                        int *chosen_out, int *status_out) {
+  peakseg_hip_set_print(to_r_console);
+  const int cap = *capacity, n = *n_dirs;
+  psd_search_row *rows =
+      (psd_search_row *)R_alloc((size_t)cap * (size_t)n, sizeof(psd_search_row));
+  PeakSegFPOP_sequential_search_batch(n, dirs, peaks_int, *verbose, cap, rows, n_out, chosen_out,
+                                      status_out);
+  for (int d = 0; d < n; d++) {
+    for (int k = 0; k < n_out[d]; k++) {
+      const size_t i = (size_t)d * (size_t)cap + (size_t)k;
+      snprintf(penalty_out[i], 40, "%s", rows[i].penalty_str);
+      iteration_out[i] = rows[i].iteration;
+      under_out[i] = rows[i].under_peaks; /* INT_MIN is R's NA_integer_ */
+      over_out[i] = rows[i].over_peaks;
+    }
+    chosen_out[d] += 1; /* 1-based for R */
+  }
+}
+
 static R_NativePrimitiveArgType PeakSegFPOP_types[] = {STRSXP, STRSXP, STRSXP};
 static R_NativePrimitiveArgType batch_types[] = {STRSXP, STRSXP, STRSXP, INTSXP, INTSXP};
 static R_NativePrimitiveArgType dir_batch_types[] = {STRSXP, STRSXP, INTSXP, INTSXP, INTSXP};
 static R_NativePrimitiveArgType search_types[] = {STRSXP, INTSXP, INTSXP, INTSXP, STRSXP,
                                                   INTSXP, INTSXP, INTSXP, INTSXP, INTSXP};
+
+static R_NativePrimitiveArgType search_batch_types[] = {STRSXP, INTSXP, INTSXP, INTSXP,
+                                                        INTSXP, STRSXP, INTSXP, INTSXP,
+                                                        INTSXP, INTSXP, INTSXP, INTSXP};
 
 static const R_CMethodDef cMethods[] = {
     {"PeakSegFPOP_interface", (DL_FUNC)&PeakSegFPOP_interface, 3, PeakSegFPOP_types},
@@ -93,6 +124,8 @@ static const R_CMethodDef cMethods[] = {
     {"PeakSegFPOP_dir_batch_interface", (DL_FUNC)&PeakSegFPOP_dir_batch_interface, 5,
      dir_batch_types},
     {"PeakSegFPOP_search_interface", (DL_FUNC)&PeakSegFPOP_search_interface, 10, search_types},
+    {"PeakSegFPOP_search_batch_interface", (DL_FUNC)&PeakSegFPOP_search_batch_interface, 12,
+     search_batch_types},
     {NULL, NULL, 0, NULL}};
 
 void R_init_PeakSegDisk(DllInfo *info) {

@@ -182,6 +182,10 @@ def test_emu_resident_search_exact_sequence(psd, oracle_det, known_answers, tmp_
     gp2.test_resident_search_exact_sequence(psd, oracle_det, known_answers, tmp_path)
 
 
+def test_emu_search_batch_equals_single_searches(psd, tmp_path):
+    gp2.test_search_batch_equals_single_searches(psd, tmp_path, n_bins=600, with_mono=False)
+
+
 def test_emu_dir_batch_cache_and_timing(psd, oracle_det, tmp_path):
     gp2.test_dir_batch_cache_and_timing(psd, oracle_det, tmp_path, 500)
 

@@ -258,6 +258,62 @@ def test_resident_search_exact_sequence(psd, oracle_det, known_answers, tmp_path
 
 
 @GPU
+def test_search_batch_equals_single_searches(psd, tmp_path, n_bins=4000, with_mono=True):
+    """sequentialSearch_dir_batch: several directories searched together -- the models of one
+    iteration in one launch -- give, directory by directory, what sequentialSearch_dir gives on
+    a copy of that directory alone: the same penalties in the same order (strings), the same
+    rows, byte-identical files.  Targets differ per directory, so the searches end after
+    different numbers of iterations (one directory is Mono27ac with its known 19-peak trace)."""
+    from peaksegdisk_amd import synthetic
+    specs = [("mono", None, 19), ("s1", 81, 7), ("s2", 82, 2), ("s3", 83, 0), ("s4", 84, 11)]
+    if not with_mono:  # the emulator rehearsal: small contigs only
+        specs = specs[1:4]
+    together, alone, targets = [], [], []
+    for name, seed, target in specs:
+        for root, acc in ((tmp_path / "together", together), (tmp_path / "alone", alone)):
+            d = root / name
+            d.mkdir(parents=True)
+            if seed is None:
+                shutil.copy(os.path.join(GOLDEN, "Mono27ac.bedGraph"), str(d / "coverage.bedGraph"))
+            else:
+                cs, ce, cnt = synthetic.poisson_coverage(n_bins + 500 * (seed - 80), seed=seed)
+                synthetic.write_bedgraph(str(d / "coverage.bedGraph"), cs, ce, cnt)
+            acc.append(str(d))
+        targets.append(target)
+    fits = psd.sequentialSearch_dir_batch(together, targets)
+    assert len(fits) == len(specs)
+    n_models = []
+    for d_t, d_a, target, fit in zip(together, alone, targets, fits):
+        ref = psd.sequentialSearch_dir(d_a, target)
+        cols = ["penalty", "segments", "peaks", "bases", "total.loss", "iteration", "under", "over"]
+        a, b = fit.others[cols], ref.others[cols]
+        assert a.shape == b.shape
+        assert [psd.paste(float(x)) for x in a["penalty"]] == [psd.paste(float(x)) for x in b["penalty"]]
+        assert a.fillna(-1).values.tolist() == b.fillna(-1).values.tolist()
+        assert int(fit.loss["peaks"].iloc[0]) == int(ref.loss["peaks"].iloc[0])
+        assert psd.paste(float(fit.loss["penalty"].iloc[0])) == psd.paste(float(ref.loss["penalty"].iloc[0]))
+        for x in a["penalty"]:
+            pen = psd.paste(float(x))
+            for suffix in ("_segments.bed", "_loss.tsv"):
+                f_t = "%s_penalty=%s%s" % (os.path.join(d_t, "coverage.bedGraph"), pen, suffix)
+                f_a = "%s_penalty=%s%s" % (os.path.join(d_a, "coverage.bedGraph"), pen, suffix)
+                assert open(f_t, "rb").read() == open(f_a, "rb").read()
+        n_models.append(len(a))
+    if with_mono:
+        assert int(fits[0].loss["peaks"].iloc[0]) == 19 and n_models[0] == 11
+    assert len(set(n_models)) > 1  # the searches did not all take the same number of rounds
+    # one target for all, everything served from the cache now
+    again = psd.sequentialSearch_dir_batch(together[-3:-1], 2)
+    assert [int(f.loss["peaks"].iloc[0]) <= 2 for f in again] == [True, True]
+    # a directory without data fails alone, with the reference's status
+    bad = tmp_path / "together" / "missing"
+    bad.mkdir()
+    with pytest.raises(psd.PeakSegError) as e:
+        psd.sequentialSearch_dir_batch([together[-2], str(bad)], 2)
+    assert e.value.status == 3
+
+
+@GPU
 def test_dir_batch_cache_and_timing(psd, oracle_det, tmp_path, n_bins=3000):
     """PeakSegFPOP_dir_batch: first call solves everything in one launch and writes
     _timing.tsv; the second is all cache hits and leaves the files untouched; a damaged file

@@ -12,6 +12,7 @@ not bench lines; these numbers go into DESIGN.md / profiles/):
   (configs[3] itself is `python bench.py --mode grid`)
 
 usage: python tools/measure_configs.py c4|c5 [size] | c3 bins target_peaks [seed [trace]]
+       | c3b [contigs [longest_bins]]
 """
 import json
 import os
@@ -101,8 +102,56 @@ def c3(n=2000000, peaks=300, seed=3, trace=None):
     return out
 
 
+def c3b(n_contigs=24, scale_hi=1e6):
+    """sequentialSearch_dir on n_contigs problem directories together (the batched search):
+    contig lengths log-uniform in [scale_hi/100, scale_hi], target = about half of each contig's
+    true peaks.  Compared with the longest contig searched alone (a copy of its directory)."""
+    import shutil
+    import peaksegdisk_amd as psd
+    from peaksegdisk_amd import synthetic
+    rng = np.random.default_rng(4)
+    lens = np.exp(rng.uniform(np.log(scale_hi / 100), np.log(scale_hi), n_contigs)).astype(int)
+    root = tempfile.mkdtemp(prefix="psd_c3b_")
+    dirs, targets = [], []
+    for k, n in enumerate(lens):
+        cs, ce, cnt = synthetic.poisson_coverage(int(n), seed=200 + k)
+        d = os.path.join(root, "chrSynth%d-0-%d" % (k, int(ce[-1])))
+        os.makedirs(d)
+        synthetic.write_bedgraph(os.path.join(d, "coverage.bedGraph"), cs, ce, cnt)
+        dirs.append(d)
+        targets.append(max(1, int(n) // 4400))
+    longest = int(np.argmax(lens))
+    alone = os.path.join(root, "alone")
+    os.makedirs(alone)
+    shutil.copy(os.path.join(dirs[longest], "coverage.bedGraph"), alone)
+    t0 = time.time()
+    fits = psd.sequentialSearch_dir_batch(dirs, targets)
+    wall = time.time() - t0
+    t0 = time.time()
+    one = psd.sequentialSearch_dir(alone, targets[longest])
+    wall_one = time.time() - t0
+    models = [int(len(f.others)) for f in fits]
+    dp_bins = int(sum(int(n) * (m - 1) for n, m in zip(lens, models)))
+    same = [psd.paste(float(x)) for x in fits[longest].others["penalty"]] == \
+        [psd.paste(float(x)) for x in one.others["penalty"]]
+    out = {"config": "c3-batched", "contigs": n_contigs, "contig_bins_min": int(lens.min()),
+           "contig_bins_max": int(lens.max()), "models_per_contig": models,
+           "found_peaks": [int(f.loss["peaks"].iloc[0]) for f in fits], "target_peaks": targets,
+           "dynamic_program_bins": dp_bins, "wall_s_all_contigs_together": wall,
+           "dp_bins_per_s_together": dp_bins / wall,
+           "wall_s_longest_contig_alone": wall_one, "models_longest_contig": models[longest],
+           "longest_contig_same_penalties_alone_and_together": same}
+    shutil.rmtree(root, ignore_errors=True)
+    return out
+
+
 if __name__ == "__main__":
     which = sys.argv[1]
+    if which == "c3b":  # c3b [contigs [longest]]
+        a = sys.argv[2:]
+        res = c3b(int(a[0]) if a else 24, float(a[1]) if len(a) > 1 else 1e6)
+        print(json.dumps(res))
+        sys.exit(0)
     if which == "c3":  # c3 bins target_peaks seed [trace]
         a = sys.argv[2:]
         res = c3(int(float(a[0])), int(a[1]), int(a[2]) if len(a) > 2 else 3,
