@@ -1447,13 +1447,16 @@ PSD_D void env_classify_lanes(bool valid, const Coef &c1, const Coef &c2, double
   const bool neither = rootp && !same_at_left && !same_at_right;
   double e_smaller = 0.0, cost_before_smaller = 0.0;
 #ifndef PSD_NO_EARLY_TAIL
-  if (ballot(neither && two_roots)) {
+  constexpr bool EARLY_TAIL = HELP; /* without a helper there is no wait to fill */
+#else
+  constexpr bool EARLY_TAIL = false;
+#endif
+  if (EARLY_TAIL && ballot(neither && two_roots)) {
     const bool on = neither && two_roots;
     e_smaller = d_exp(on ? smaller_log_mean : 0.0);
     cost_before_smaller = get_cost(d, d_log(on ? (ea + e_smaller) / 2 : 1.0));
     if (!on) e_smaller = 0.0;
   }
-#endif
 #ifdef PSD_HELPER_WAVES
   if (HELP) {
     if (root_posted) {
@@ -1475,9 +1478,7 @@ PSD_D void env_classify_lanes(bool valid, const Coef &c1, const Coef &c2, double
   PSD_PROF_ITERS(PROF_IT_SMALL, it_small);
   PSD_PROF_ITERS(PROF_IT_LARGE, it_large);
   /* phase G, the part that needs both roots */
-#ifdef PSD_NO_EARLY_TAIL
-  if (neither && two_roots) e_smaller = d_exp(smaller_log_mean);
-#endif
+  if (!EARLY_TAIL && neither && two_roots) e_smaller = d_exp(smaller_log_mean);
   double first_log_mean = PSD_INF, second_log_mean = PSD_INF;
   if (neither && two_roots) {
     bool larger_inside = a < larger_log_mean && larger_log_mean < b;
@@ -1504,22 +1505,21 @@ PSD_D void env_classify_lanes(bool valid, const Coef &c1, const Coef &c2, double
   double cost_diff_other = 0.0;
   if (need_other) cost_diff_other = get_cost(d, x_other);
   double cost_diff_before = 0.0;
-#ifndef PSD_NO_EARLY_TAIL
-  if (need_before) cost_diff_before = cost_before_smaller;
-  /* the larger root is the first crossing: exp(first crossing) and the cost before it anew */
-  const bool redo = need_before && first_log_mean != smaller_log_mean;
-  if (ballot(redo)) {
-    const double e_first = d_exp(redo ? first_log_mean : 0.0);
-    const double c_before = get_cost(d, d_log(redo ? (ea + e_first) / 2 : 1.0));
-    if (redo) cost_diff_before = c_before;
+  if (EARLY_TAIL) {
+    if (need_before) cost_diff_before = cost_before_smaller;
+    /* the larger root is the first crossing: exp(first crossing) and the cost before it anew */
+    const bool redo = need_before && first_log_mean != smaller_log_mean;
+    if (ballot(redo)) {
+      const double e_first = d_exp(redo ? first_log_mean : 0.0);
+      const double c_before = get_cost(d, d_log(redo ? (ea + e_first) / 2 : 1.0));
+      if (redo) cost_diff_before = c_before;
+    }
+  } else {
+    /* exp(first crossing) unless it is the value already computed */
+    double e_first = e_smaller;
+    if (need_before && first_log_mean != smaller_log_mean) e_first = d_exp(first_log_mean);
+    if (need_before) cost_diff_before = get_cost(d, d_log((ea + e_first) / 2));
   }
-#else
-  /* exp(first crossing) unless it is the value already computed */
-  double e_first = e_smaller;
-  if (need_before && first_log_mean != smaller_log_mean) e_first = d_exp(first_log_mean);
-  if (need_before) cost_diff_before = get_cost(d, d_log((ea + e_first) / 2));
-  (void)cost_before_smaller;
-#endif
 
   PSD_PROF_ADD(PROF_C_TAIL);
   /* ---- decisions (no more transcendentals) ---- */
