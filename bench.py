@@ -331,7 +331,10 @@ def main():
         alg_bytes /= world
         bins_launch /= world
         extra = {"kernel_build": stats.get("kernel_build"),
-                 "hbm_bytes_resident": stats.get("hbm_bytes")}
+                 "hbm_bytes_resident": stats.get("hbm_bytes"),
+                 # 0: every cost function stored; K: the checkpointed store (picked when the
+                 # full store of rank 0's share would not fit its HBM)
+                 "checkpoint_interval": stats.get("checkpoint_interval")}
 
     if rank == 0:
         units = units_per_step * args.steps
