@@ -457,8 +457,14 @@ def test_full_size_grid_properties(psd, oracle_det, tmp_path):
     pset.close()
 
 
+# PSD_FUZZ_EXTRA="4000:11,4000:12": more (cases, seed) runs of the fuzz test, for soak runs on a
+# GPU box (profiles/r02/fuzz_soak.log); the suite itself runs the first pair only
+_FUZZ_RUNS = [(300, 5)] + [tuple(int(v) for v in item.split(":"))
+                           for item in os.environ.get("PSD_FUZZ_EXTRA", "").split(",") if item]
+
+
 @GPU
-@pytest.mark.parametrize("n_cases,seed", [(300, 5)])
+@pytest.mark.parametrize("n_cases,seed", _FUZZ_RUNS)
 def test_fuzz_tiny_problems(psd, oracle_det, tmp_path, n_cases, seed):
     """Many tiny random problems in one problem set (ragged lengths 1..40, zeros, repeated
     counts, increasing/decreasing runs, wide count ranges, penalties from 0 to 1e6): the rare
