@@ -752,9 +752,11 @@ PSD_D void forward_body(const DeviceArgs &a) {
                                cum_weight_new));
         cur = cur_hbm;
         /* With the lists in HBM the two waves first meet at the workgroup barrier, so that the
-         * flag barrier below finds the other wave there already: a wave that polls while the
-         * other one works through lists in HBM costs half as much again per data point
-         * (config 5, 1e5 data points: 7.6 s -> 11.4 s; profiles/r02/ab_step_barrier.log).
+         * flag barrier below finds the other wave there already: a wave that polled LDS while
+         * the other one worked through lists in HBM with FLAT instructions (issued to the LDS
+         * pipeline too) cost half as much again per data point (config 5, 1e5 data points:
+         * 7.6 s -> 11.4 s; profiles/r02/ab_step_barrier.log).  The lists are reached with
+         * global_* instructions now and polling is harmless; the barrier stays as a guard.
          * in_hbm is the same in both waves. */
         block_sync_cold(chain);
       }
