@@ -810,6 +810,13 @@ extern "C" int PeakSegFPOP_sequential_search_batch(int n_dirs, char **problem_di
     if (n_rows) n_rows[d] = 0;
     if (chosen_row) chosen_row[d] = -1;
   }
+  /* a directory listed twice would have two searches write the same files in the same launch */
+  for (int d = 0; d < n_dirs; d++)
+    for (int e = 0; e < d; e++)
+      if (ss[(size_t)d].status == 0 && real_path(bedGraph[(size_t)d]) == real_path(bedGraph[(size_t)e])) {
+        set_error("sequential search: problem directory %s is listed twice", problem_dirs[d]);
+        ss[(size_t)d].status = ERROR_SEARCH_ARGUMENTS;
+      }
   const double t0 = wall_now();
   int round = 0, launches = 0;
   for (;;) {

@@ -305,6 +305,10 @@ def test_search_batch_equals_single_searches(psd, tmp_path, n_bins=4000, with_mo
     # one target for all, everything served from the cache now
     again = psd.sequentialSearch_dir_batch(together[-3:-1], 2)
     assert [int(f.loss["peaks"].iloc[0]) <= 2 for f in again] == [True, True]
+    # a directory listed twice is refused (two searches would write the same files at once)
+    with pytest.raises(psd.PeakSegError) as e:
+        psd.sequentialSearch_dir_batch([together[-2], together[-2]], 2)
+    assert e.value.status == 15
     # a directory without data fails alone, with the reference's status
     bad = tmp_path / "together" / "missing"
     bad.mkdir()
