@@ -128,13 +128,20 @@ def test_sequential_search_without_gpu(native, tmp_path):
         api.sequentialSearch_dir(str(d), 19)
     assert e.value.status == 12
     # the batched search: every directory fails alone with the same status
-    dirs = (ctypes.c_char_p * 2)(os.fsencode(str(d)), os.fsencode(str(d)))
+    d2 = tmp_path / "prob2"
+    d2.mkdir()
+    shutil.copy(os.path.join(GOLDEN, "Mono27ac.bedGraph"), str(d2 / "coverage.bedGraph"))
+    dirs = (ctypes.c_char_p * 2)(os.fsencode(str(d)), os.fsencode(str(d2)))
     peaks = (ctypes.c_int * 2)(19, 3)
     rows2 = (native.PsdSearchRow * 16)()
     n2, chosen2, st2 = (ctypes.c_int * 2)(), (ctypes.c_int * 2)(), (ctypes.c_int * 2)()
     rc = native.lib.PeakSegFPOP_sequential_search_batch(2, dirs, peaks, 0, 8, rows2, n2, chosen2,
                                                         st2)
     assert rc == native.ERROR_NO_HIP_DEVICE and list(st2) == [12, 12] and list(chosen2) == [-1, -1]
+    # the same directory twice is refused for the second one
+    dirs = (ctypes.c_char_p * 2)(os.fsencode(str(d)), os.fsencode(str(d)))
+    native.lib.PeakSegFPOP_sequential_search_batch(2, dirs, peaks, 0, 8, rows2, n2, chosen2, st2)
+    assert list(st2) == [12, native.ERROR_SEARCH_ARGUMENTS]
     with pytest.raises(api.PeakSegError) as e:
         api.sequentialSearch_dir_batch([str(d)], 19)
     assert e.value.status == 12
