@@ -13,6 +13,7 @@ import pytest
 
 import test_gpu_parity as gp
 import test_gpu_round2 as gp2
+import test_gpu_round3 as gp3
 from conftest import ROOT
 
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
@@ -205,3 +206,26 @@ def test_emu_checkpointed_store_limits(psd, tmp_path, monkeypatch):
 
 def test_emu_mixed_launch(psd, tmp_path, monkeypatch):
     gp2.test_mixed_launch_of_unequal_contigs(psd, tmp_path, monkeypatch, 500, 40, 63)
+
+
+def test_emu_solve_grid(psd, tmp_path):
+    gp3.test_solve_grid_on_device(psd, tmp_path, n_contigs=4, scale=0.0006, n_pen=5)
+
+
+def test_emu_adversarial_counts(psd, oracle_det, tmp_path):
+    gp3.test_adversarial_counts_1e5(psd, oracle_det, tmp_path, n_bins=1200, want_max=0,
+                                    spill_from=700)
+
+
+def test_emu_worst_case_vignette_grid(psd, oracle_det, tmp_path):
+    gp3.test_worst_case_vignette_grid(psd, oracle_det, tmp_path, sizes=(10, 100, 300))
+
+
+def test_emu_sequential_search_synthetic(psd, tmp_path):
+    gp3.test_sequential_search_on_a_1e6_bin_contig(psd, tmp_path, n_bins=1500, peaks_int=2)
+
+
+def test_emu_write_failures_dp_branch(psd, tmp_path, monkeypatch):
+    monkeypatch.setenv("PSD_TEST_NATIVE_LIB",
+                       os.path.join(EMU_DIR, "_build", "libpeaksegdisk_emu.so"))
+    gp3.test_write_failures_injected_on_the_dp_branch(psd, tmp_path, n_bins=600)

@@ -91,22 +91,24 @@ def check_against_libm_files(pset, i, pen, bg, cs, ce, n_bins):
 @GPU
 def test_endpoints_vs_glibc_arithmetic_1e6_x64(psd, tmp_path):
     """BASELINE.json configs[1] at full size against the arithmetic the reference itself
-    uses: 16 of the 64 penalties (every 4th, both ends included) solved by oracle_cli_libm in
-    a process pool while the GPU solves the grid."""
+    uses: ALL 64 penalties solved by oracle_cli_libm in a process pool while the GPU solves the
+    grid (round 2 sampled 17); every 8th penalty also by the deterministic build, to report how
+    many stored functions differ in piece count between the two arithmetics."""
     from peaksegdisk_amd import ProblemSet, synthetic
     n_bins = 1000000
     cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=1)
     pens = synthetic.penalty_grid(64)
-    pick = sorted(set(list(range(0, 64, 4)) + [63]))
+    pick = list(range(64))
     bg = str(tmp_path / "coverage.bedGraph")
     write_bedgraph_chunked(bg, cs, ce, cnt)
-    workers = max(1, min(len(pick), len(os.sched_getaffinity(0))))
+    import bench
+    workers = max(1, min(len(pick) + 8, bench.host_cores()))
     t0 = time.time()
     with ThreadPoolExecutor(max_workers=workers) as pool:
         futs = [pool.submit(run_cli, CLI_LIBM, bg, pens[i], str(tmp_path / ("l%d.db" % i)))
                 for i in pick]
         # the deterministic build for four of them: piece-count divergence det vs glibc
-        div_pick = [pick[1], pick[6], pick[11], pick[-1]]
+        div_pick = [4, 12, 20, 28, 36, 44, 52, 63]
         ddir = tmp_path / "det"
         ddir.mkdir()
         dbg = str(ddir / "coverage.bedGraph")
@@ -144,16 +146,17 @@ def test_endpoints_vs_glibc_arithmetic_1e6_x64(psd, tmp_path):
 
 @GPU
 def test_endpoints_vs_glibc_arithmetic_1e7_x64(psd, tmp_path):
-    """The north_star size: one 1e7-bin contig x 64 penalties on one GPU, two penalties checked
-    against oracle_cli_libm (which needs about two minutes each; both run while the GPU works)."""
+    """The north_star size: one 1e7-bin contig x 64 penalties on one GPU, four penalties
+    checked against oracle_cli_libm (which needs two to three minutes each; they run while the
+    GPU works)."""
     from peaksegdisk_amd import ProblemSet, synthetic
     n_bins = 10000000
     cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=1)
     pens = synthetic.penalty_grid(64)
-    pick = [9, 44]
+    pick = [9, 27, 44, 60]
     bg = str(tmp_path / "coverage.bedGraph")
     write_bedgraph_chunked(bg, cs, ce, cnt)
-    with ThreadPoolExecutor(max_workers=2) as pool:
+    with ThreadPoolExecutor(max_workers=len(pick)) as pool:
         futs = [pool.submit(run_cli, CLI_LIBM, bg, pens[i], str(tmp_path / ("l%d.db" % i)))
                 for i in pick]
         pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, float(p)) for p in pens])

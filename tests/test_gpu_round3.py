@@ -1,0 +1,359 @@
+"""Round-3 parity tests on an MI355X (through the C ABI): the BASELINE.json configurations
+that round 2 had only measured, now compared with the oracle under the driver's `-m gpu` run.
+
+  * configs[3]: `parallel.solve_grid` (the dealing + packing + gather layer) on 24 contigs x 64
+    penalties, EVERY problem against the oracle's files; pack/unpack through device tensors;
+  * configs[4]: the Worst_case vignette's adversarial counts at 1e5 data points (every step
+    through the HBM spill path) and the vignette's own grid (penalties 0, 1e2, 1e4, 1e6 x
+    N = 10, 100, 1000 on increasing counts and on Mono27ac prefixes);
+  * configs[2]: `sequentialSearch_dir` on a 1e6-bin contig, penalty string for penalty string
+    against the same loop driven by the oracle (which runs while the GPU searches);
+  * write failures of the three output files injected with RLIMIT_FSIZE
+    (reference: tests/testthat/test-TRAVIS-out-of-disk-space.R:37-94 mounts a full tmpfs).
+"""
+import os
+import shutil
+import subprocess
+import sys
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ORACLE_DIR, ROOT, read_loss, read_segments
+
+GPU = pytest.mark.gpu
+CLI_DET = os.path.join(ORACLE_DIR, "_build", "oracle_cli_det")
+
+
+@pytest.fixture(scope="module")
+def psd():
+    import __graft_entry__ as entry
+    entry.build_hip()
+    entry.build_oracle()
+    import peaksegdisk_amd
+    from peaksegdisk_amd import _native
+    assert _native.lib.peakseg_hip_device_count() >= 1, "no HIP device: GPU tests need an MI355X"
+    return peaksegdisk_amd
+
+
+def run_cli(cli, bg, pen, db):
+    st = subprocess.run([cli, bg, pen, db], stdout=subprocess.DEVNULL).returncode
+    assert st == 0, (cli, pen, st)
+    if os.path.exists(db):
+        os.unlink(db)
+
+
+def check_tables_vs_oracle_files(bg, pen, cs, ce, start, mean, summary):
+    """One problem's segment table and summary = [n_segments, n_equality, max_intervals,
+    total_intervals, best_cost] against the files the deterministic oracle wrote."""
+    segs = read_segments("%s_penalty=%s_segments.bed" % (bg, pen))
+    assert len(segs) == len(start) == int(summary[0]), pen
+    got_start = np.where(start < 0, int(cs[0]), ce[np.maximum(start, 0)])
+    assert np.array_equal(np.array([s[1] for s in segs]), got_start), pen
+    assert [s[4] for s in segs] == ["%g" % v for v in mean], pen
+    loss = read_loss("%s_penalty=%s_loss.tsv" % (bg, pen)).split("\t")
+    n = len(ce)
+    assert int(loss[1]) == int(summary[0]) and int(loss[7]) == int(summary[1]), pen
+    assert float(loss[9]) == summary[2] and float(loss[8]) == summary[3] / (2.0 * n), pen
+    assert loss[5] == "%.20g" % summary[4], pen
+
+
+@GPU
+def test_solve_grid_on_device(psd, tmp_path, n_contigs=24, scale=0.01, n_pen=64):
+    """BASELINE.json configs[3] on one rank: parallel.solve_grid deals 24 contigs (lengths
+    log-uniform, bench.grid_contig_lengths) x 64 penalties = 1536 problems, solves them in
+    one device problem set and returns them through the gather layer.  EVERY problem's
+    seg_start, "%g" means and summary equal the deterministic oracle's files (a process pool
+    writes those while the GPU works)."""
+    import bench
+    from peaksegdisk_amd import synthetic
+    from peaksegdisk_amd.parallel import solve_grid
+    lengths = bench.grid_contig_lengths(n_contigs, scale)
+    pen_str = synthetic.penalty_grid(n_pen)
+    data, contigs = [], []
+    for c, n in enumerate(lengths):
+        cs, ce, cnt = synthetic.poisson_coverage(n, seed=101 + c)
+        data.append((cs, ce, cnt))
+        contigs.append((cnt, (ce - cs).astype(np.int32)))
+
+    def oracle_job(job):
+        c, lo, hi = job
+        cs, ce, cnt = data[c]
+        bg = str(tmp_path / ("c%d_%d" % (c, lo)) / "coverage.bedGraph")
+        os.makedirs(os.path.dirname(bg))
+        synthetic.write_bedgraph(bg, cs, ce, cnt)
+        for pen in pen_str[lo:hi]:
+            run_cli(CLI_DET, bg, pen, bg + ".db")
+        return c, lo, hi, bg
+    # longest contigs first, each contig's penalties in 4 slices: an even pool
+    step = max(1, n_pen // 4)
+    jobs = [(c, lo, min(n_pen, lo + step)) for c in np.argsort(lengths)[::-1].tolist()
+            for lo in range(0, n_pen, step)]
+    workers = max(1, bench.host_cores())
+    stats = {}
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        futs = [pool.submit(oracle_job, j) for j in jobs]
+        out = solve_grid(contigs, [float(p) for p in pen_str], None, 0, stats=stats)
+        done = [f.result() for f in futs]
+    assert len(out) == n_contigs * n_pen
+    for c, lo, hi, bg in done:
+        cs, ce, cnt = data[c]
+        for p in range(lo, hi):
+            res = out[(c, p)]
+            check_tables_vs_oracle_files(bg, pen_str[p], cs, ce, res["seg_start"],
+                                         res["seg_mean"], res["summary"])
+    assert stats["problems"] == n_contigs * n_pen
+
+
+@GPU
+def test_pack_tables_through_device_tensors(psd):
+    """The gather's payload (parallel.pack_tables) survives the trip numpy -> HBM -> numpy
+    bit for bit, empty and ragged tables included: what each rank's RCCL gather moves."""
+    import torch
+    from peaksegdisk_amd.parallel import pack_tables, unpack_tables
+    rng = np.random.default_rng(3)
+    tables = []
+    for n in [0, 1, 5, 70000, 3, 0, 1234]:
+        tables.append((rng.integers(-2, 2 ** 31 - 1, n).astype(np.int32),
+                       rng.standard_normal(n) * 10.0 ** rng.integers(-300, 300, n)))
+    rows, start, mean = pack_tables(tables)
+    dev = torch.device("cuda", 0)
+    back = [torch.from_numpy(a).to(dev).clone().cpu().numpy() for a in (rows, start, mean)]
+    got = unpack_tables(*back)
+    assert len(got) == len(tables)
+    for (s0, m0), (s1, m1) in zip(tables, got):
+        assert np.array_equal(s0, s1) and np.array_equal(m0.view(np.uint64), m1.view(np.uint64))
+
+
+@GPU
+def test_adversarial_counts_1e5(psd, oracle_det, tmp_path, n_bins=100000, want_max=741,
+                                spill_from=2000):
+    """BASELINE.json configs[4] at a tenth of its length: count = 1..N
+    (vignettes/Worst_case.Rmd:26-28), penalty 100: every data point beyond the first few
+    hundred runs with the lists in the HBM spill area (functions of up to 741 pieces).  Whole
+    output files equal the oracle's; the oracle solves while the GPU does."""
+    from peaksegdisk_amd import ProblemSet, synthetic
+    cs, ce, cnt = synthetic.increasing_coverage(n_bins)
+    bg = str(tmp_path / "o" / "coverage.bedGraph")
+    os.makedirs(os.path.dirname(bg))
+    synthetic.write_bedgraph(bg, cs, ce, cnt)
+    th = threading.Thread(target=run_cli, args=(CLI_DET, bg, "100", bg + ".db"))
+    th.start()
+    gbg = str(tmp_path / "g" / "coverage.bedGraph")
+    os.makedirs(os.path.dirname(gbg))
+    shutil.copy(bg, gbg)
+    pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, 100.0)])
+    pset.solve()
+    r = pset.result(0)
+    start, mean = pset.segments(0)
+    pset.close()
+    assert r.status == 0
+    if want_max:
+        assert r.max_intervals == want_max
+    assert r.spill_steps >= n_bins - spill_from and r.max_intervals > 128
+    # and through the file-level boundary: byte-identical files
+    from peaksegdisk_amd import _native
+    st = _native.lib.PeakSegFPOP_disk(gbg.encode(), b"100", (gbg + ".db").encode())
+    assert st == 0
+    th.join()
+    check_tables_vs_oracle_files(bg, "100", cs, ce, start, mean,
+                                 [r.n_segments, r.n_equality_constraints, r.max_intervals,
+                                  r.total_intervals, r.best_cost])
+    for suffix in ("_segments.bed", "_loss.tsv"):
+        assert open(gbg + "_penalty=100" + suffix, "rb").read() == \
+            open(bg + "_penalty=100" + suffix, "rb").read()
+
+
+@GPU
+def test_worst_case_vignette_grid(psd, oracle_det, tmp_path, sizes=(10, 100, 1000)):
+    """vignettes/Worst_case.Rmd:22-41: penalties {0, 1e2, 1e4, 1e6} x N {10, 100, 1000} on
+    increasing counts AND on prefixes of Mono27ac; the vignette states that the large penalty
+    on increasing data reaches the (N+1)/2-interval worst case (:48-64).  One batch call;
+    every file equals the oracle's, and the worst case is what it says."""
+    from peaksegdisk_amd import _native, synthetic
+    mono = [l.split("\t") for l in open(os.path.join(GOLDEN, "Mono27ac.bedGraph")).read()
+            .splitlines()]
+    pens = ["0", "100", "10000", "1000000"]
+    files, gfiles = [], []
+    for n in sizes:
+        cs, ce, cnt = synthetic.increasing_coverage(n)
+        for kind in ("increasing", "mono"):
+            for root, keep in ((tmp_path / "o", files), (tmp_path / "g", gfiles)):
+                d = root / ("%s_%d" % (kind, n))
+                d.mkdir(parents=True)
+                bg = str(d / "coverage.bedGraph")
+                if kind == "increasing":
+                    synthetic.write_bedgraph(bg, cs, ce, cnt)
+                else:
+                    with open(bg, "w") as f:
+                        f.write("".join("\t".join(r) + "\n" for r in mono[:n]))
+                keep.append((kind, n, bg))
+    import ctypes
+    bgs = [bg for _, _, bg in gfiles for _ in pens]
+    ps = [p for _ in gfiles for p in pens]
+    dbs = [bg + "_penalty=%s.db" % p for bg, p in zip(bgs, ps)]
+    n = len(bgs)
+    arr = lambda xs: (ctypes.c_char_p * n)(*[x.encode() for x in xs])
+    status = (ctypes.c_int * n)()
+    assert _native.lib.PeakSegFPOP_disk_batch(n, arr(bgs), arr(ps), arr(dbs), status) == 0
+    assert list(status) == [0] * n
+    for (kind, size, obg), (_, _, gbg) in zip(files, gfiles):
+        for pen in pens:
+            assert oracle_det.solve(obg, pen) == 0
+            for suffix in ("_segments.bed", "_loss.tsv"):
+                a = open("%s_penalty=%s%s" % (gbg, pen, suffix), "rb").read()
+                b = open("%s_penalty=%s%s" % (obg, pen, suffix), "rb").read()
+                assert a == b, (kind, size, pen, suffix)
+            # the database left behind (DP branch only) has the size of the reference's
+            gdb, odb = "%s_penalty=%s.db" % (gbg, pen), "%s_penalty=%s.db" % (obg, pen)
+            assert os.path.exists(gdb) == os.path.exists(odb), (kind, size, pen)
+            if os.path.exists(odb):
+                assert os.path.getsize(gdb) == os.path.getsize(odb), (kind, size, pen)
+        if kind == "increasing":
+            # Worst_case.Rmd:48-64: with a penalty, the mean number of intervals grows linearly
+            # with N on this data (it stays near 3 at penalty 0), bounded by (N+1)/2
+            loss = [read_loss("%s_penalty=%s_loss.tsv" % (gbg, p)).split("\t") for p in pens]
+            mean_int = [float(c[8]) for c in loss]
+            assert mean_int[0] < 3 and max(mean_int) <= (size + 1) / 2.0
+            if size >= 100:
+                assert max(mean_int[1:]) > size / 6.0
+            if size >= 1000:
+                assert max(float(c[9]) for c in loss) > 128  # beyond LDS: the spill path
+
+
+def _oracle_search(problem_dir, peaks_int, cli=CLI_DET):
+    """sequentialSearch_dir (R/sequentialSearch_dir.R:31-99) driven by the oracle executable."""
+    from peaksegdisk_amd.api import paste
+    bg = os.path.join(problem_dir, "coverage.bedGraph")
+
+    def model(pen_str):
+        run_cli(cli, bg, pen_str, "%s_penalty=%s.db" % (bg, pen_str))
+        c = read_loss("%s_penalty=%s_loss.tsv" % (bg, pen_str)).split("\t")
+        return {"penalty": pen_str, "peaks": int(c[2]), "total.loss": float(c[6])}
+    with ThreadPoolExecutor(max_workers=2) as pool:  # iteration 1: two independent models
+        trace = list(pool.map(model, ["0", "Inf"]))
+    over, under = trace[0], trace[1]
+    while True:
+        if peaks_int in (under["peaks"], over["peaks"]):
+            break
+        pen = (over["total.loss"] - under["total.loss"]) / (under["peaks"] - over["peaks"])
+        if pen < 0:
+            break
+        m = model(paste(pen))
+        trace.append(m)
+        if m["peaks"] in (under["peaks"], over["peaks"]):
+            break
+        if m["peaks"] < peaks_int:
+            under = m
+        else:
+            over = m
+    return trace
+
+
+@GPU
+def test_sequential_search_on_a_1e6_bin_contig(psd, tmp_path, n_bins=1000000, peaks_int=500):
+    """BASELINE.json configs[2] at a tenth of its length: sequentialSearch_dir on a 1e6-bin
+    synthetic contig.  The resident driver must ask for the models the reference's loop asks
+    for: same penalty strings in the same order, same peaks, and the chosen model's files
+    byte-identical to the oracle's (the oracle-driven loop runs in a thread meanwhile)."""
+    from peaksegdisk_amd import synthetic
+    cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=1)
+    gdir = tmp_path / "gpu" / "chrSynth-0-1"
+    odir = tmp_path / "oracle" / "chrSynth-0-1"
+    for d in (gdir, odir):
+        d.mkdir(parents=True)
+    bg = str(odir / "coverage.bedGraph")
+    with open(bg, "w") as f:
+        for o in range(0, n_bins, 500000):
+            f.write("".join("chrSynth\t%d\t%d\t%d\n" % t for t in zip(
+                cs[o:o + 500000].tolist(), ce[o:o + 500000].tolist(), cnt[o:o + 500000].tolist())))
+    os.link(bg, str(gdir / "coverage.bedGraph"))
+    box = {}
+    th = threading.Thread(target=lambda: box.update(trace=_oracle_search(str(odir), peaks_int)))
+    t0 = time.time()
+    th.start()
+    fit = psd.sequentialSearch_dir(str(gdir), peaks_int)
+    gpu_s = time.time() - t0
+    th.join()
+    trace = box["trace"]
+    got_pen = [psd.paste(float(p)) for p in fit.others["penalty"]]
+    assert got_pen == [m["penalty"] for m in trace]
+    assert list(fit.others["peaks"]) == [m["peaks"] for m in trace]
+    chosen = psd.paste(float(fit.loss["penalty"].iloc[0]))
+    for suffix in ("_segments.bed", "_loss.tsv"):
+        assert open("%s_penalty=%s%s" % (str(gdir / "coverage.bedGraph"), chosen, suffix),
+                    "rb").read() == open("%s_penalty=%s%s" % (bg, chosen, suffix), "rb").read()
+    print("search of %d bins: %d models, %.1f s on the GPU path, %.1f s with the oracle loop"
+          % (n_bins, len(trace), gpu_s, time.time() - t0))
+
+
+_FSIZE_CHILD = r"""
+import ctypes, os, resource, signal, sys
+sys.path.insert(0, %(root)r)
+from peaksegdisk_amd import _native
+if os.environ.get("PSD_TEST_NATIVE_LIB"):  # CPU rehearsal: kernels under the SIMT emulator
+    _native.lib = _native.declare(ctypes.CDLL(os.environ["PSD_TEST_NATIVE_LIB"]))
+lib = _native.lib
+bg, pen, limit, warm = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+if warm != "-":  # touch the device (and whatever files the runtime creates) before the limit
+    assert lib.PeakSegFPOP_disk(warm.encode(), pen.encode(), (warm + ".db").encode()) == 0
+signal.signal(signal.SIGXFSZ, signal.SIG_IGN)  # write() then fails with EFBIG, as on a full disk
+if limit >= 0:
+    resource.setrlimit(resource.RLIMIT_FSIZE, (limit, limit))
+st = lib.PeakSegFPOP_disk(bg.encode(), pen.encode(), (bg + ".db").encode())
+buf = ctypes.create_string_buffer(2000)
+lib.PeakSegFPOP_status_message(st, bg.encode(), pen.encode(), (bg + ".db").encode(), buf, 2000)
+sys.stdout.write("%%d\n%%s\n" %% (st, buf.value.decode()))
+"""
+
+
+def run_with_file_size_limit(bg, pen, limit, warm="-"):
+    """PeakSegFPOP_disk(bg, pen, bg.db) in a child process whose RLIMIT_FSIZE is `limit` bytes
+    (-1: unlimited); returns (status, message of PeakSegFPOP_status_message)."""
+    p = subprocess.run([sys.executable, "-c", _FSIZE_CHILD % {"root": ROOT}, bg, pen, str(limit),
+                        warm], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    st, msg = p.stdout.split("\n")[:2]
+    return int(st), msg
+
+
+def output_sizes(bg, pen):
+    pre = "%s_penalty=%s" % (bg, pen)
+    db = bg + ".db"
+    return (os.path.getsize(pre + "_loss.tsv"), os.path.getsize(pre + "_segments.bed"),
+            os.path.getsize(db) if os.path.exists(db) else 0)
+
+
+@GPU
+def test_write_failures_injected_on_the_dp_branch(psd, tmp_path, n_bins=3000):
+    """test-TRAVIS-out-of-disk-space.R:37-94 fills a tiny tmpfs (needs sudo); here a child
+    process lowers RLIMIT_FSIZE before the call.  As in the reference's own test, a dynamic
+    program under a size limit fails on its cost-function database (code 7, "unable to write to
+    cost function database file", :37-41) -- the database of a problem is always larger than
+    its two text files, and the reference writes it first -- whatever the limit; the loss /
+    segments write errors (8, 11) are reached on the branch without a database (penalty "Inf",
+    :84-91): tests/test_host_layers_cpu.py::test_write_failures_on_the_host_only_branch, and
+    with unwritable paths in tests/golden/known_answers.json."""
+    from peaksegdisk_amd import synthetic
+    cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=77)
+    warm = str(tmp_path / "warm.bedGraph")
+    synthetic.write_bedgraph(warm, cs[:200], ce[:200], cnt[:200])
+    ref = str(tmp_path / "unlimited.bedGraph")
+    synthetic.write_bedgraph(ref, cs, ce, cnt)
+    for pen in ("0", "5000"):
+        assert run_with_file_size_limit(ref, pen, -1, warm) == (0, "")
+        loss, seg, db = output_sizes(ref, pen)
+        assert 0 < loss and 0 < seg and max(loss, seg) < db
+        for name, limit in (("tiny", 8), ("between", (max(loss, seg) + db) // 2), ("just", db - 1)):
+            bg = str(tmp_path / ("%s_%s.bedGraph" % (name, pen)))
+            synthetic.write_bedgraph(bg, cs, ce, cnt)
+            st, msg = run_with_file_size_limit(bg, pen, limit, warm)
+            assert st == 7, (name, pen, st, msg)
+            assert msg == "unable to write to cost function database file " + bg + ".db"
+        # a limit of exactly the database's size is enough
+        bg = str(tmp_path / ("fits_%s.bedGraph" % pen))
+        synthetic.write_bedgraph(bg, cs, ce, cnt)
+        assert run_with_file_size_limit(bg, pen, db, warm) == (0, "")

@@ -230,3 +230,29 @@ def test_bench_single_rank_line_on_emulator():
     assert cb["all_cores"]["cores"] >= 1 and cb["all_cores"]["value"] > 0 and cb["cpu_model"]
     assert "all 3 penalties" in cb["sample"]
     assert d["value_incl_upload"] > 0 and d["value_incl_upload"] <= d["value"] * 1.0001
+
+
+def test_write_failures_on_the_host_only_branch(tmp_path):
+    """tests/testthat/test-TRAVIS-out-of-disk-space.R:37-94 needs a full filesystem (a tmpfs
+    mounted with sudo); a child process under RLIMIT_FSIZE gives the same write errors.  Here
+    the closed-form branch (penalty "Inf", drv:224-243: no device work): the loss file cannot
+    be written -> code 8, only the segments file cannot -> code 11, with the reference's
+    messages (interface.cpp:38-46).  The DP branch is covered on the GPU
+    (test_gpu_round3.test_write_failures_injected_on_the_dp_branch)."""
+    from test_gpu_round3 import output_sizes, run_with_file_size_limit
+    chrom = "chr" + "x" * 90  # a segments row longer than the loss row
+    rows = "".join("%s\t%d\t%d\t%d\n" % (chrom, 10 * i, 10 * i + 10, c)
+                   for i, c in enumerate([2, 10, 14, 13]))
+    ref = str(tmp_path / "unlimited.bedGraph")
+    open(ref, "w").write(rows)
+    assert run_with_file_size_limit(ref, "Inf", -1) == (0, "")
+    loss, seg, db = output_sizes(ref, "Inf")
+    assert 0 < loss < seg and db == 0
+    for name, limit, code, text in [
+            ("loss", loss - 1, 8, "unable to write to loss output file"),
+            ("segments", (loss + seg) // 2, 11, "unable to write to segments output file")]:
+        bg = str(tmp_path / (name + ".bedGraph"))
+        open(bg, "w").write(rows)
+        st, msg = run_with_file_size_limit(bg, "Inf", limit)
+        assert st == code, (name, st, msg)
+        assert text in msg and bg + "_penalty=Inf" in msg, msg
