@@ -546,11 +546,20 @@ PSD_COLD_DEV int take_spill_slot(const DeviceArgs &a, int chain) {
 
 /* ---- checkpointed store ----------------------------------------
  * Checkpoint slot k of a problem holds the two live functions after data point (k+1) K: per
- * slot 2 + 12 cap doubles {cum_weight, -, then per chain Lin, Log, Con, mn, mx, prv} and
- * 2 + 2 cap ints {n_up, n_down, then per chain data_i}. */
+ * slot 4 + 12 cap doubles {cum_weight, -, overflow offsets of the two chains (bit patterns),
+ * then per chain Lin, Log, Con, mn, mx, prv} and 2 + 2 cap ints {n_up, n_down, then per chain
+ * data_i}.  A function with more than cap pieces lives in the overflow pool (6 n doubles from
+ * 6 off, n ints from off) and the slot only holds its offset. */
+constexpr int CKPT_HDR_F64 = 4, CKPT_HDR_I32 = 2;
+PSD_D size_t ckpt_f64_at(const DeviceArgs &a, long long slot) {
+  return (size_t)slot * (CKPT_HDR_F64 + 12 * (size_t)a.ckpt_cap);
+}
+PSD_D size_t ckpt_i32_at(const DeviceArgs &a, long long slot) {
+  return (size_t)slot * (CKPT_HDR_I32 + 2 * (size_t)a.ckpt_cap);
+}
 PSD_D GlobalList ckpt_list(const DeviceArgs &a, long long slot, int chain) {
   const size_t cap = (size_t)a.ckpt_cap;
-  gdouble *f = (gdouble *)(a.ckpt_f64 + (size_t)slot * (2 + 12 * cap) + 2 + (size_t)chain * 6 * cap);
+  gdouble *f = (gdouble *)(a.ckpt_f64 + ckpt_f64_at(a, slot) + CKPT_HDR_F64 + (size_t)chain * 6 * cap);
   GlobalList r;
   r.Lin_ = f;
   r.Log_ = f + cap;
@@ -558,38 +567,97 @@ PSD_D GlobalList ckpt_list(const DeviceArgs &a, long long slot, int chain) {
   r.mn_ = f + 3 * cap;
   r.mx_ = f + 4 * cap;
   r.prv_ = f + 5 * cap;
-  r.di_ = (gint *)(a.ckpt_i32 + (size_t)slot * (2 + 2 * cap) + 2 + (size_t)chain * cap);
+  r.di_ = (gint *)(a.ckpt_i32 + ckpt_i32_at(a, slot) + CKPT_HDR_I32 + (size_t)chain * cap);
   return r;
 }
-/* this chain's function (LDS list `id`, n pieces) and the cumulated weight -> slot k */
+/* n pieces of the overflow pool from piece offset off */
+PSD_D GlobalList ckpt_overflow_list(const DeviceArgs &a, unsigned long long off, int n) {
+  gdouble *f = (gdouble *)(a.ckpt_ovf_f64 + (size_t)off * 6);
+  const size_t m = (size_t)n;
+  GlobalList r;
+  r.Lin_ = f;
+  r.Log_ = f + m;
+  r.Con_ = f + 2 * m;
+  r.mn_ = f + 3 * m;
+  r.mx_ = f + 4 * m;
+  r.prv_ = f + 5 * m;
+  r.di_ = (gint *)(a.ckpt_ovf_i32 + (size_t)off);
+  return r;
+}
+/* Room in the overflow pool for the functions of this checkpoint that exceed ckpt_cap (cold:
+ * adversarial data only).  Both chain waves call it with the same counts; chain 0 takes the
+ * room with one atomic and publishes it.  Returns the offset of the first such function (the
+ * up function's if it is one), ~0 when the pool is exhausted -- in both waves alike. */
+PSD_COLD_DEV unsigned long long ckpt_take_overflow(const DeviceArgs &a, int chain, int n_up,
+                                                   int n_down) {
+  chain = uniform_i(chain);
+  n_up = uniform_i(n_up);
+  n_down = uniform_i(n_down);
+  const unsigned long long want = (unsigned long long)(n_up > a.ckpt_cap ? n_up : 0) +
+                                  (unsigned long long)(n_down > a.ckpt_cap ? n_down : 0);
+  if (chain == 0 && lane_id() == 0) {
+    unsigned long long off = atomicAdd(a.ckpt_ovf_next, want);
+    g_sm.ckpt_ovf = off + want <= a.ckpt_ovf_cap ? off : ~0ull;
+  }
+  block_sync(chain);
+  const unsigned long long off = psd_d2u(uniform_d(psd_u2d(g_sm.ckpt_ovf)));
+  block_sync(chain); /* the word is free again before anyone can come back here */
+  return off;
+}
+/* this chain's function (list `id`, n pieces, in LDS or in the problem's slot of the HBM spill
+ * pool) and the cumulated weight -> checkpoint k; ovf: this chain's room in the overflow pool
+ * when n > ckpt_cap */
 PSD_COLD_DEV void ckpt_save(const DeviceArgs &a, int p, int k, int chain, int id, int n,
-                            double cum_weight) {
+                            double cum_weight, int in_hbm, int spill_slot, unsigned long long ovf) {
   p = uniform_i(p);
   k = uniform_i(k);
   chain = uniform_i(chain);
   n = uniform_i(n);
+  id = uniform_i(id);
+  spill_slot = uniform_i(spill_slot);
+  ovf = psd_d2u(uniform_d(psd_u2d(ovf)));
   const long long slot = a.prob_ckpt_off[p] + k;
-  copy_list_across(lds_list(uniform_i(id)), n, ckpt_list(a, slot, chain));
+  const GlobalList dst = n > a.ckpt_cap ? ckpt_overflow_list(a, ovf, n) : ckpt_list(a, slot, chain);
+  if (uniform_i(in_hbm)) {
+    copy_list_across(global_list(a, spill_slot, id), n, dst);
+  } else {
+    copy_list_across(lds_list(id), n, dst);
+  }
   if (lane_id() == 0) {
-    const size_t cap = (size_t)a.ckpt_cap;
-    a.ckpt_i32[(size_t)slot * (2 + 2 * cap) + (size_t)chain] = n;
-    if (chain == 0) a.ckpt_f64[(size_t)slot * (2 + 12 * cap)] = uniform_d(cum_weight);
+    a.ckpt_i32[ckpt_i32_at(a, slot) + (size_t)chain] = n;
+    a.ckpt_f64[ckpt_f64_at(a, slot) + 2 + (size_t)chain] = psd_u2d(ovf);
+    if (chain == 0) a.ckpt_f64[ckpt_f64_at(a, slot)] = uniform_d(cum_weight);
   }
 }
-/* slot k -> LDS list `id`; returns the piece count */
-PSD_COLD_DEV int ckpt_load(const DeviceArgs &a, int p, int k, int chain, int id) {
+/* piece count of a chain's function in checkpoint k */
+PSD_COLD_DEV int ckpt_count(const DeviceArgs &a, int p, int k, int chain) {
+  const long long slot = a.prob_ckpt_off[uniform_i(p)] + uniform_i(k);
+  return uniform_i(a.ckpt_i32[ckpt_i32_at(a, slot) + (size_t)uniform_i(chain)]);
+}
+/* checkpoint k -> list `id` (LDS, or the problem's spill slot when to_hbm); returns the piece
+ * count */
+PSD_COLD_DEV int ckpt_load(const DeviceArgs &a, int p, int k, int chain, int id, int to_hbm,
+                           int spill_slot) {
   p = uniform_i(p);
   k = uniform_i(k);
   chain = uniform_i(chain);
+  id = uniform_i(id);
+  spill_slot = uniform_i(spill_slot);
   const long long slot = a.prob_ckpt_off[p] + k;
-  const size_t cap = (size_t)a.ckpt_cap;
-  const int n = uniform_i(a.ckpt_i32[(size_t)slot * (2 + 2 * cap) + (size_t)chain]);
-  copy_list_across(ckpt_list(a, slot, chain), n, lds_list(uniform_i(id)));
+  const int n = uniform_i(a.ckpt_i32[ckpt_i32_at(a, slot) + (size_t)chain]);
+  const unsigned long long ovf =
+      psd_d2u(uniform_d(a.ckpt_f64[ckpt_f64_at(a, slot) + 2 + (size_t)chain]));
+  const GlobalList src = n > a.ckpt_cap ? ckpt_overflow_list(a, ovf, n) : ckpt_list(a, slot, chain);
+  if (uniform_i(to_hbm)) {
+    copy_list_across(src, n, global_list(a, spill_slot, id));
+  } else {
+    copy_list_across(src, n, lds_list(id));
+  }
   return n;
 }
 PSD_COLD_DEV double ckpt_cum_weight(const DeviceArgs &a, int p, int k) {
   const long long slot = a.prob_ckpt_off[uniform_i(p)] + uniform_i(k);
-  return a.ckpt_f64[(size_t)slot * (2 + 12 * (size_t)a.ckpt_cap)];
+  return a.ckpt_f64[ckpt_f64_at(a, slot)];
 }
 
 /* PSD_KERNEL_WAVES_PER_EU (throughput build): keep the kernel's own register use within the
@@ -810,11 +878,19 @@ PSD_D void forward_body(const DeviceArgs &a) {
     cum_weight_prev_i = cum_weight_i;
     b = nb;
     if (CKPT && t == next_ckpt) { /* forward pass: keep the two live functions */
-      if (in_hbm) {
-        status = PST_CKPT_SPILL; /* both chains: in_hbm is the same in the two waves */
-        break;
+      /* both counts are visible to both waves since the barrier of this data point */
+      const int n_up = uniform_i(g_sm.n[b]), n_down = uniform_i(g_sm.n[2 + b]);
+      unsigned long long ovf = 0;
+      if (n_up > a.ckpt_cap || n_down > a.ckpt_cap) { /* beyond a slot: the overflow pool */
+        ovf = psd_d2u(uniform_d(psd_u2d(ckpt_take_overflow(*a.self, chain, n_up, n_down))));
+        if (ovf == ~0ull) {
+          status = PST_CKPT_FULL; /* in both waves */
+          break;
+        }
+        if (chain == 1 && n_up > a.ckpt_cap) ovf += (unsigned long long)n_up;
       }
-      ckpt_save(*a.self, p, t / K - 1, chain, 2 * chain + b, n_new, cum_weight_i);
+      ckpt_save(*a.self, p, t / K - 1, chain, 2 * chain + b, n_new, cum_weight_i, in_hbm ? 1 : 0,
+                spill_slot, ovf);
       next_ckpt += K;
     }
   }
@@ -879,7 +955,19 @@ PSD_D void forward_body(const DeviceArgs &a) {
     if (lane == 0) g_sm.n[2 * chain] = g_sm.n[2 * chain + 1] = 0;
   } else {
     device_fence();
-    const int n_ck = uniform_i(ckpt_load(*a.self, p, c - 1, chain, 2 * chain));
+    /* functions that do not fit LDS: the block starts with the lists in the HBM spill area
+     * (the same decision in both waves: both counts are in the checkpoint) */
+    in_hbm = uniform_i(ckpt_count(*a.self, p, c - 1, 0)) > LDS_CAP ||
+             uniform_i(ckpt_count(*a.self, p, c - 1, 1)) > LDS_CAP;
+    if (in_hbm && spill_slot < 0) {
+      spill_slot = uniform_i(take_spill_slot(*a.self, chain));
+      if (spill_slot < 0) {
+        status = PST_SPILL_FULL;
+        break;
+      }
+    }
+    const int n_ck = uniform_i(ckpt_load(*a.self, p, c - 1, chain, 2 * chain, in_hbm ? 1 : 0,
+                                         spill_slot));
     if (lane == 0) g_sm.n[2 * chain] = n_ck;
     cum_weight_i = uniform_d(ckpt_cum_weight(*a.self, p, c - 1));
     cum_weight_prev_i = cum_weight_i;

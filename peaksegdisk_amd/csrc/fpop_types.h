@@ -26,7 +26,9 @@ enum {
   PST_REF_THROW = 3,     /* the reference would throw / loop / read a list sentinel */
   PST_BACKTRACK = 4,     /* findMean found no piece (the reference would never return) */
   PST_SPILL_FULL = 5,    /* no free slot in the HBM spill pool: host retries with more slots */
-  PST_CKPT_SPILL = 6,    /* checkpointed store: a function to checkpoint has outgrown LDS */
+  PST_CKPT_SPILL = 6,    /* (rounds 1-2: a function to checkpoint had outgrown LDS; no longer raised) */
+  PST_CKPT_FULL = 7,     /* checkpointed store: the overflow pool for checkpoints of functions with
+                            more than ckpt_cap pieces is exhausted: host retries with a larger one */
 };
 
 struct ProbResult {
@@ -91,13 +93,20 @@ struct DeviceArgs {
    * per-step records, only the two live functions after every K-th data point; the decoding
    * recomputes, block of K data points by block, the records it walks through, into a private
    * region of the arena (ckpt_region pieces per chain).  fn_ref then holds 2 (K+1) entries per
-   * problem.  Per checkpoint: 12 ckpt_cap + 2 doubles and 2 ckpt_cap + 2 ints. */
+   * problem.  Per checkpoint: 12 ckpt_cap + 4 doubles and 2 ckpt_cap + 2 ints.  A function with
+   * more than ckpt_cap pieces (adversarial data, lists in the HBM spill area) is checkpointed into
+   * the overflow pool instead -- n pieces taken with one atomic, their offset kept in the slot's
+   * header -- so that checkpoints never limit the size of a function. */
   int ckpt_interval;
   int ckpt_cap;
   unsigned long long ckpt_region;
   const long long *prob_ckpt_off; /* first checkpoint slot of each problem */
   double *ckpt_f64;
   int *ckpt_i32;
+  double *ckpt_ovf_f64;            /* overflow pool: 6 doubles + 1 int per piece */
+  int *ckpt_ovf_i32;
+  unsigned long long ckpt_ovf_cap; /* pieces */
+  unsigned long long *ckpt_ovf_next;
   /* mixed launch: host-visible count of latency-build workgroups that have started (the host
    * holds the packed part back until they all have their CUs); nullptr otherwise */
   int *started;

@@ -93,6 +93,7 @@ struct SharedBlock {
   int serial[2];
   int spill_slot; /* slot of the HBM spill pool taken by this problem (take_spill_slot) */
   int bt_next;    /* checkpointed store: block the decoding needs next, -1 = done */
+  unsigned long long ckpt_ovf; /* checkpointed store: room taken in the overflow pool */
 #ifdef PSD_HELPER_WAVES
   Mail mail[2];
 #endif

@@ -228,6 +228,12 @@ bool touch_db(FileProblem &fp) {
   return true;
 }
 
+std::string real_path(const std::string &path) {
+  char buf[PATH_MAX];
+  if (realpath(path.c_str(), buf)) return buf;
+  return path;
+}
+
 int solve_files(int n, FileProblem *fps) {
   /* PEAKSEG_HIP_TIMING=1: where a call spends its time, on stderr */
   const bool timing = getenv("PEAKSEG_HIP_TIMING") != nullptr;
@@ -241,9 +247,26 @@ int solve_files(int n, FileProblem *fps) {
   std::vector<Coverage> covs;
   std::map<std::string, int> cov_of_path;
   std::map<std::string, int> cov_status;
+  /* A (bedGraph, penalty string) pair listed twice names the same two output files: the second
+   * copy is not solved (its writer thread would race the first one's on the same paths); it
+   * receives the first one's status and figures at the end. */
+  std::vector<int> dup_of((size_t)n, -1);
+  {
+    std::map<std::pair<std::string, std::string>, int> seen;
+    for (int i = 0; i < n; i++) {
+      auto key = std::make_pair(real_path(fps[i].bedGraph), std::string(fps[i].penalty_str));
+      auto it = seen.find(key);
+      if (it == seen.end()) {
+        seen[key] = i;
+      } else {
+        dup_of[(size_t)i] = it->second;
+      }
+    }
+  }
   /* 1. penalties, then inputs (validation order of drv:145-209) */
   for (int i = 0; i < n; i++) {
     FileProblem &fp = fps[i];
+    if (dup_of[(size_t)i] >= 0) continue;
     fp.status = parse_penalty(fp.penalty_str, fp.is_Inf, fp.penalty);
     if (fp.status) continue;
     std::string path = fp.bedGraph;
@@ -266,7 +289,7 @@ int solve_files(int n, FileProblem *fps) {
   std::vector<int> dp;
   for (int i = 0; i < n; i++) {
     FileProblem &fp = fps[i];
-    if (fp.status) continue;
+    if (fp.status || dup_of[(size_t)i] >= 0) continue;
     const Coverage &cv = covs[(size_t)fp.cov];
     open_outputs(fp);
     if (fp.is_Inf || cv.min_log_mean == cv.max_log_mean) {
@@ -339,7 +362,24 @@ int solve_files(int n, FileProblem *fps) {
   int first = 0;
   for (int i = 0; i < n; i++) {
     FileProblem &fp = fps[i];
+    if (dup_of[(size_t)i] >= 0) continue;
     settle_status(fp);
+  }
+  for (int i = 0; i < n; i++) {
+    FileProblem &fp = fps[i];
+    if (dup_of[(size_t)i] >= 0) {
+      const FileProblem &o = fps[dup_of[(size_t)i]];
+      fp.status = o.status;
+      fp.n_segments = o.n_segments;
+      fp.n_peaks = o.n_peaks;
+      fp.bases = o.bases;
+      fp.total_loss = o.total_loss;
+      fp.db_bytes = o.db_bytes;
+      /* its own database name, if it has one, is left as the first copy's is */
+      if (fp.status == 0 && o.dp_index >= 0 && strcmp(fp.db, o.db) != 0 && touch_db(fp) &&
+          truncate(fp.db, (off_t)fp.db_bytes) != 0)
+        fp.status = ERROR_WRITING_COST_FUNCTIONS;
+    }
     if (fp.status && !first) first = fp.status;
   }
   return first;
@@ -467,12 +507,6 @@ bool write_timing(const std::string &pre, const char *penalty_str, double megaby
   std::string t = r_paste_double(strtod(penalty_str, nullptr)) + "\t" +
                   r_paste_double(megabytes) + "\t" + r_paste_double(seconds) + "\n";
   return write_whole_file(pre + "_timing.tsv", t);
-}
-
-std::string real_path(const std::string &path) {
-  char buf[PATH_MAX];
-  if (realpath(path.c_str(), buf)) return buf;
-  return path;
 }
 
 bool file_exists(const std::string &path) {

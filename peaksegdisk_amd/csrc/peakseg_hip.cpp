@@ -294,6 +294,7 @@ struct psd_problem_set {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev2 = nullptr;
   int *started = nullptr; /* pinned host word: latency-build workgroups of a mixed launch */
+  bool mixed_wait_timed_out = false; /* the wait for them ran into its bound once: recorded, not repeated */
   std::vector<void *> allocs;
   unsigned long long bytes = 0;
 };
@@ -425,6 +426,35 @@ int alloc_spill(psd_problem_set *s, int slots) {
     return st;
   s->spill_slots = slots;
   s->d.spill_slots = slots;
+  return 0;
+}
+
+void free_ckpt_overflow(psd_problem_set *s) {
+  void *ptrs[2] = {s->d.ckpt_ovf_f64, s->d.ckpt_ovf_i32};
+  for (void *q : ptrs) {
+    if (!q) continue;
+    for (size_t i = 0; i < s->allocs.size(); i++) {
+      if (s->allocs[i] == q) {
+        s->allocs.erase(s->allocs.begin() + (long)i);
+        break;
+      }
+    }
+    (void)hipFree(q);
+  }
+  s->bytes -= s->d.ckpt_ovf_cap * 52ull;
+  s->d.ckpt_ovf_f64 = nullptr;
+  s->d.ckpt_ovf_i32 = nullptr;
+  s->d.ckpt_ovf_cap = 0;
+}
+
+/* Overflow pool of the checkpointed store: checkpoints of functions too long for a slot. */
+int alloc_ckpt_overflow(psd_problem_set *s, unsigned long long pieces) {
+  if (pieces < 1024) pieces = 1024;
+  int st;
+  if ((st = dev_alloc(s, &s->d.ckpt_ovf_f64, (size_t)pieces * 6)) ||
+      (st = dev_alloc(s, &s->d.ckpt_ovf_i32, (size_t)pieces)))
+    return st;
+  s->d.ckpt_ovf_cap = pieces;
   return 0;
 }
 
@@ -624,11 +654,22 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
   d.ckpt_region = 0;
   d.ckpt_f64 = nullptr;
   d.ckpt_i32 = nullptr;
+  d.ckpt_ovf_f64 = nullptr;
+  d.ckpt_ovf_i32 = nullptr;
+  d.ckpt_ovf_cap = 0;
+  d.ckpt_ovf_next = nullptr;
   if (K > 0) {
     const size_t cap = (size_t)d.ckpt_cap;
     const size_t slots = (size_t)(ckpt_off > 0 ? ckpt_off : 1);
-    if ((st = dev_alloc(s, &d.ckpt_f64, slots * (2 + 12 * cap))) ||
-        (st = dev_alloc(s, &d.ckpt_i32, slots * (2 + 2 * cap)))) {
+    if ((st = dev_alloc(s, &d.ckpt_f64, slots * (4 + 12 * cap))) ||
+        (st = dev_alloc(s, &d.ckpt_i32, slots * (2 + 2 * cap))) ||
+        (st = dev_alloc(s, &d.ckpt_ovf_next, (size_t)1)) ||
+        /* checkpoints of functions with more than ckpt_cap pieces (adversarial data):
+         * PEAKSEG_HIP_CKPT_OVERFLOW pieces to start with (default 2^18 = 13 MB), four times as
+         * many and a rerun whenever that proves too small */
+        (st = alloc_ckpt_overflow(s, env_bytes("PEAKSEG_HIP_CKPT_OVERFLOW")
+                                         ? env_bytes("PEAKSEG_HIP_CKPT_OVERFLOW")
+                                         : (1ull << 18)))) {
       peakseg_hip_problem_set_destroy(s);
       return st;
     }
@@ -706,7 +747,8 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
   }
 #endif
   if (e == hipSuccess) e = hipEventCreate(&s->ev2);
-  if (e == hipSuccess) e = hipHostMalloc((void **)&s->started, sizeof(int), hipHostMallocDefault);
+  if (e == hipSuccess)
+    e = hipHostMalloc((void **)&s->started, sizeof(int), hipHostMallocCoherent | hipHostMallocMapped);
   for (auto &ev : s->ev)
     if (e == hipSuccess) e = hipEventCreate(&ev);
   if (e != hipSuccess) {
@@ -766,8 +808,16 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
     s->n_lat_mixed = best_l;
   }
   for (int attempt = 0;; attempt++) {
+    if (s->ckpt_interval > 0 &&
+        s->d.ar_cap < s->d.ckpt_region * 2ull * (unsigned long long)s->n_problems) {
+      set_error("checkpointed store: arena of %llu pieces is smaller than its %d regions of %llu",
+                s->d.ar_cap, 2 * s->n_problems, s->d.ckpt_region);
+      return ERROR_DEVICE_MEMORY;
+    }
     HIP_TRY(hipMemsetAsync(s->d.ar_next_chunk, 0, sizeof(unsigned long long), s->stream));
     HIP_TRY(hipMemsetAsync(s->d.spill_next, 0, sizeof(int), s->stream));
+    if (s->d.ckpt_ovf_next)
+      HIP_TRY(hipMemsetAsync(s->d.ckpt_ovf_next, 0, sizeof(unsigned long long), s->stream));
     HIP_TRY(hipMemcpyAsync(const_cast<psd::DeviceArgs *>(s->d.self), &s->d, sizeof(psd::DeviceArgs),
                            hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipEventRecord(s->ev[0], s->stream));
@@ -795,11 +845,16 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
                            dim3(psd::lat::FORWARD_THREADS), 0, s->stream2, d_lat);
       HIP_TRY(hipGetLastError());
       (void)hipStreamQuery(s->stream2); /* submit now */
-      {
+      if (attempt == 0 && !s->mixed_wait_timed_out) { /* reruns and later solves after a time-out do not wait again */
         const auto t0 = std::chrono::steady_clock::now();
         while (__atomic_load_n(s->started, __ATOMIC_ACQUIRE) < L &&
-               std::chrono::steady_clock::now() - t0 < std::chrono::seconds(2))
+               std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(500))
           std::this_thread::yield();
+        if (__atomic_load_n(s->started, __ATOMIC_ACQUIRE) < L) {
+          s->mixed_wait_timed_out = true;
+          set_error("mixed launch: %d of %d latency-build workgroups had not started after 0.5 s; "
+                    "the packed part was launched anyway", L - *s->started, L);
+        }
       }
       if (s->ckpt_interval > 0)
         hipLaunchKernelGGL(psd::thr::fpop_forward_ckpt_kernel, dim3((unsigned)d_thr.n_problems),
@@ -840,16 +895,31 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
       s->arena_used = chunks << s->d.ar_chunk_log2;
       if (s->arena_used > s->d.ar_cap) s->arena_used = s->d.ar_cap;
     }
-    bool arena_full = false, spill_full = false;
+    bool arena_full = false, spill_full = false, ckpt_full = false;
+    int longest_function = 0;
     for (auto &r : s->results) {
       arena_full = arena_full || r.status == psd::PST_ARENA_FULL;
       spill_full = spill_full || r.status == psd::PST_SPILL_FULL;
+      ckpt_full = ckpt_full || r.status == psd::PST_CKPT_FULL;
+      if (r.max_intervals > longest_function) longest_function = r.max_intervals;
     }
-    if (!arena_full && !spill_full) break;
+    if (!arena_full && !spill_full && !ckpt_full) break;
     if (attempt >= 8) {
       set_error("cost-function arena (%llu pieces) / spill pool (%d slots) still too small after "
                 "%d reruns", s->arena_pieces, s->spill_slots, attempt);
       return ERROR_DEVICE_MEMORY;
+    }
+    if (ckpt_full) {
+      unsigned long long bigger = s->d.ckpt_ovf_cap * 4ull;
+      free_ckpt_overflow(s);
+      const unsigned long long fit = arena_fit(s) * 20ull / 52ull;
+      if (bigger > fit) {
+        set_error("checkpointed store: an overflow pool of %llu pieces does not fit (free HBM / "
+                  "PEAKSEG_HIP_MAX_BYTES)", bigger);
+        return ERROR_DEVICE_MEMORY;
+      }
+      int st = alloc_ckpt_overflow(s, bigger);
+      if (st) return st;
     }
     if (spill_full) {
       /* more problems spilled at once than the pool has slots: four times the slots */
@@ -870,9 +940,14 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
       /* grow and rerun the whole set: at least twice the size, and what the problems' progress
        * says the whole set needs (pieces handed out so far / share of the data points done) */
       unsigned long long bigger = s->arena_pieces * 2ull;
+      const unsigned long long old_ppf = s->ckpt_pieces_per_fn;
       if (s->ckpt_interval > 0) {
-        /* checkpointed store: a block's records outgrew a wave's region -- twice the region */
+        /* checkpointed store: a block's records outgrew a wave's region -- twice the region,
+         * or at once what the longest function of the forward pass asks for (K + 1 functions of
+         * that length always fit then) when that is more */
         s->ckpt_pieces_per_fn *= 2ull;
+        if (s->ckpt_pieces_per_fn < (unsigned long long)longest_function)
+          s->ckpt_pieces_per_fn = (unsigned long long)longest_function;
         s->d.ckpt_region = (unsigned long long)(s->ckpt_interval + 1) * s->ckpt_pieces_per_fn;
         bigger = s->d.ckpt_region * 2ull * (unsigned long long)s->n_problems;
       } else {
@@ -891,6 +966,18 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
       unsigned long long old_pieces = s->arena_pieces;
       free_arena(s);
       unsigned long long fit = arena_fit(s);
+      if (s->ckpt_interval > 0 && bigger > fit) {
+        /* The kernel indexes region (2 p + chain) of ckpt_region pieces without looking at
+         * ar_cap: an arena clipped to what fits would be written beyond its end.  No clipping
+         * here: the regions either fit or the set does not. */
+        set_error("checkpointed store: %llu pieces per region x %d regions (%llu bytes) do not "
+                  "fit (free HBM / PEAKSEG_HIP_MAX_BYTES)", s->d.ckpt_region, 2 * s->n_problems,
+                  bigger * 20ull);
+        s->ckpt_pieces_per_fn = old_ppf;
+        s->d.ckpt_region = (unsigned long long)(s->ckpt_interval + 1) * s->ckpt_pieces_per_fn;
+        (void)alloc_arena(s, old_pieces < fit ? old_pieces : fit);
+        return ERROR_DEVICE_MEMORY;
+      }
       if (bigger > fit) bigger = fit;
       if (bigger <= old_pieces) {
         set_error("cost-function arena cannot grow beyond %llu pieces (free HBM / "
@@ -906,14 +993,8 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
   for (int p = 0; p < s->n_problems; p++) {
     const psd::ProbResult &r = s->results[(size_t)p];
     if (r.status != 0 && first == 0) {
-      if (r.status == psd::PST_CKPT_SPILL) {
-        set_error("problem %d: a cost function outgrew LDS at a checkpoint (data point %d); the "
-                  "checkpointed store cannot hold it -- rerun with the full store "
-                  "(PEAKSEG_HIP_NO_CHECKPOINT=1)", p, r.step_reached);
-      } else {
-        set_error("problem %d: kernel status %d (wave error bits %d) at data point %d", p,
-                  r.status, r.wave_err, r.step_reached);
-      }
+      set_error("problem %d: kernel status %d (wave error bits %d) at data point %d", p, r.status,
+                r.wave_err, r.step_reached);
       first = ERROR_DEVICE_SOLVER;
     }
   }

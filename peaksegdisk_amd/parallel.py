@@ -44,13 +44,18 @@ def unpack_tables(rows, start, mean):
     return out
 
 
-def gather_segment_tables(tables, dist=None, device=None):
+def gather_segment_tables(tables, dist=None, device=None, always_collective=False):
     """Gather every rank's segment tables on rank 0.
 
     dist is torch.distributed (already initialised) or None for a single process.  Returns on
     rank 0 a list over ranks of lists of (seg_start, seg_mean); on other ranks None.
-    Protocol: all_gather of the per-rank row totals, then one padded gather per array."""
-    if dist is None or dist.get_world_size() == 1:
+    Protocol: one all_gather of the per-rank totals (rows, segments),
+    then every other rank sends its three packed arrays to rank 0 at their exact sizes --
+    grouped point-to-point sends/receives (ncclSend/ncclRecv inside one group on RCCL; xGMI is
+    point-to-point, so this is the natural shape and no rank is padded to the largest table:
+    penalty ~ 0 on a 1e7-bin contig is 5.5 M rows, a large penalty a few thousand).
+    always_collective: run the all_gather even for a single rank (tests: RCCL on one GPU)."""
+    if dist is None or (dist.get_world_size() == 1 and not always_collective):
         return [tables]
     import torch
     world = dist.get_world_size()
@@ -61,30 +66,25 @@ def gather_segment_tables(tables, dist=None, device=None):
     metas = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(metas, meta)
     metas = [m.cpu().tolist() for m in metas]
-    max_rows = max(m[0] for m in metas)
-    max_seg = max(m[1] for m in metas)
-
-    def padded(a, n, dtype):
-        t = torch.zeros(max(n, 1), dtype=dtype, device=dev)
-        if len(a):
-            t[:len(a)] = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        return t
-
-    payload = [padded(rows, max_rows, torch.int64), padded(start, max_seg, torch.int32),
-               padded(mean, max_seg, torch.float64)]
-    gathered = []
-    for t in payload:
-        bufs = [torch.zeros_like(t) for _ in range(world)] if rank == 0 else None
-        dist.gather(t, bufs, dst=0)
-        gathered.append(bufs)
+    dtypes = (torch.int64, torch.int32, torch.float64)
+    ops, bufs = [], {}
+    if rank == 0:
+        for r in range(1, world):
+            n_rows, n_seg = metas[r]
+            bufs[r] = [torch.empty(n, dtype=dt, device=dev)
+                       for n, dt in zip((n_rows, n_seg, n_seg), dtypes)]
+            ops += [dist.P2POp(dist.irecv, t, r) for t in bufs[r] if t.numel() > 0]
+    else:
+        payload = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (rows, start, mean)]
+        ops = [dist.P2POp(dist.isend, t, 0) for t in payload if t.numel() > 0]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     if rank != 0:
         return None
-    out = []
-    for r in range(world):
-        n_rows, n_seg = metas[r]
-        out.append(unpack_tables(gathered[0][r][:n_rows].cpu().numpy(),
-                                 gathered[1][r][:n_seg].cpu().numpy(),
-                                 gathered[2][r][:n_seg].cpu().numpy()))
+    out = [tables]
+    for r in range(1, world):
+        out.append(unpack_tables(*[t.cpu().numpy() for t in bufs[r]]))
     return out
 
 

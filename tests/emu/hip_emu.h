@@ -108,6 +108,8 @@ hipError_t hipFree(void *p);
 hipError_t hipHostMalloc(void **p, size_t n, unsigned flags);
 hipError_t hipHostFree(void *p);
 #define hipHostMallocDefault 0u
+#define hipHostMallocMapped 2u
+#define hipHostMallocCoherent 0x40000000u
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t s);
 hipError_t hipMemset(void *p, int v, size_t n);

@@ -201,7 +201,8 @@ def test_emu_checkpointed_store(psd, oracle_det, tmp_path, monkeypatch):
 
 
 def test_emu_checkpointed_store_limits(psd, tmp_path, monkeypatch):
-    gp2.test_checkpointed_store_region_regrowth_and_limits(psd, tmp_path, monkeypatch, 1500, 0)
+    gp2.test_checkpointed_store_region_regrowth_and_limits(psd, tmp_path, monkeypatch, 1500, 0, 1000,
+                                                           (("thr", ""), ("lat", "1024")))
 
 
 def test_emu_mixed_launch(psd, tmp_path, monkeypatch):
@@ -222,10 +223,14 @@ def test_emu_worst_case_vignette_grid(psd, oracle_det, tmp_path):
 
 
 def test_emu_sequential_search_synthetic(psd, tmp_path):
-    gp3.test_sequential_search_on_a_1e6_bin_contig(psd, tmp_path, n_bins=1500, peaks_int=2)
+    gp3.test_sequential_search_on_a_long_contig(psd, tmp_path, n_bins=1500, peaks_int=2)
 
 
 def test_emu_write_failures_dp_branch(psd, tmp_path, monkeypatch):
     monkeypatch.setenv("PSD_TEST_NATIVE_LIB",
                        os.path.join(EMU_DIR, "_build", "libpeaksegdisk_emu.so"))
     gp3.test_write_failures_injected_on_the_dp_branch(psd, tmp_path, n_bins=600)
+
+
+def test_emu_batch_with_duplicate_problems(psd, oracle_det, tmp_path):
+    gp3.test_batch_with_duplicate_problems(psd, oracle_det, tmp_path, n_bins=400)

@@ -611,11 +611,13 @@ def test_checkpointed_store_equals_full_store(psd, oracle_det, tmp_path, monkeyp
 
 @GPU
 def test_checkpointed_store_region_regrowth_and_limits(psd, tmp_path, monkeypatch, n_bins=6000,
-                                                       auto_bins=200000):
-    """A block whose records outgrow the wave's region makes the host double the regions and
-    rerun; a function that has outgrown LDS at a checkpoint is refused with a clear message
-    (the checkpointed store keeps LDS-sized functions only); a memory cap that the full store
-    would exceed selects the checkpointed store by itself."""
+                                                       auto_bins=200000, adv_bins=3000,
+                                                       adv_builds=(("lat", ""), ("thr", ""),
+                                                                   ("lat", "1024"))):
+    """A block whose records outgrow the wave's region makes the host enlarge the regions and
+    rerun (a clean error when the cap forbids it); functions that have outgrown LDS are
+    checkpointed too (overflow pool) and recomputed from there; a memory cap that the full
+    store would exceed selects the checkpointed store by itself."""
     from peaksegdisk_amd import ProblemSet, synthetic
     cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=12)
     w = (ce - cs).astype(np.int32)
@@ -634,12 +636,53 @@ def test_checkpointed_store_region_regrowth_and_limits(psd, tmp_path, monkeypatc
                                                               want[1].view(np.uint64))
     ck.close()
     monkeypatch.delenv("PEAKSEG_HIP_PIECES_PER_FUNCTION")
-    # adversarial data: functions of hundreds of pieces at the checkpoints
-    c2s, c2e, c2 = synthetic.increasing_coverage(3000)
-    bad = ProblemSet([(c2, (c2e - c2s).astype(np.int32))], [(0, 100.0)])
-    with pytest.raises(RuntimeError, match="outgrew LDS at a checkpoint"):
-        bad.solve()
-    bad.close()
+    # adversarial data: functions of hundreds of pieces at the checkpoints (lists in the HBM
+    # spill area): they are checkpointed into the overflow pool, the blocks that hold segment
+    # ends start from there in HBM mode, and the result equals the full store's.  Both builds;
+    # an overflow pool that is too small at first (one rerun with four times the pool).
+    c2s, c2e, c2 = synthetic.increasing_coverage(adv_bins)
+    w2 = (c2e - c2s).astype(np.int32)
+    monkeypatch.delenv("PEAKSEG_HIP_CHECKPOINT")
+    monkeypatch.setenv("PEAKSEG_HIP_NO_CHECKPOINT", "1")
+    full = ProblemSet([(c2, w2)], [(0, 100.0), (0, 2.0)])
+    full.solve()
+    want2 = [(full.result(i).max_intervals, full.result(i).total_intervals, full.result(i).best_cost)
+             + full.segments(i) for i in range(2)]
+    assert want2[0][0] > 128 and len(want2[0][3]) > 3
+    full.close()
+    monkeypatch.delenv("PEAKSEG_HIP_NO_CHECKPOINT")
+    monkeypatch.setenv("PEAKSEG_HIP_CHECKPOINT", "256")
+    for build, pool in adv_builds:
+        monkeypatch.setenv("PEAKSEG_HIP_VARIANT", build)
+        if pool:
+            monkeypatch.setenv("PEAKSEG_HIP_CKPT_OVERFLOW", pool)
+        adv = ProblemSet([(c2, w2)], [(0, 100.0), (0, 2.0)])
+        adv.solve()
+        assert adv.checkpoint_interval == 256 and adv.kernel_build == build
+        for i in range(2):
+            r = adv.result(i)
+            assert r.status == 0, (build, i, r.kernel_status)
+            assert (r.max_intervals, r.total_intervals, r.best_cost) == want2[i][:3]
+            s1, m1 = adv.segments(i)
+            assert np.array_equal(s1, want2[i][3])
+            assert np.array_equal(m1.view(np.uint64), want2[i][4].view(np.uint64))
+        adv.close()
+    monkeypatch.delenv("PEAKSEG_HIP_VARIANT")
+    monkeypatch.delenv("PEAKSEG_HIP_CKPT_OVERFLOW", raising=False)
+    # Regrowth that the memory cap cannot hold must end with a clean error, never with an arena
+    # smaller than the regions the kernel indexes: the same adversarial data, a
+    # cap just above what the set holds after its first, far too small, allocation.
+    monkeypatch.setenv("PEAKSEG_HIP_PIECES_PER_FUNCTION", "1")
+    probe = ProblemSet([(c2, w2)], [(0, 100.0)])
+    held = probe.hbm_bytes
+    probe.close()
+    monkeypatch.setenv("PEAKSEG_HIP_MAX_BYTES", str(held + 4096))
+    capped = ProblemSet([(c2, w2)], [(0, 100.0)])
+    with pytest.raises(RuntimeError, match="do not fit|cannot grow"):
+        capped.solve()
+    capped.close()
+    monkeypatch.delenv("PEAKSEG_HIP_MAX_BYTES")
+    monkeypatch.delenv("PEAKSEG_HIP_PIECES_PER_FUNCTION")
     monkeypatch.delenv("PEAKSEG_HIP_CHECKPOINT")
     if not auto_bins:
         return

@@ -6,7 +6,7 @@ that round 2 had only measured, now compared with the oracle under the driver's 
   * configs[4]: the Worst_case vignette's adversarial counts at 1e5 data points (every step
     through the HBM spill path) and the vignette's own grid (penalties 0, 1e2, 1e4, 1e6 x
     N = 10, 100, 1000 on increasing counts and on Mono27ac prefixes);
-  * configs[2]: `sequentialSearch_dir` on a 1e6-bin contig, penalty string for penalty string
+  * configs[2]: `sequentialSearch_dir` on a 5e5-bin contig, penalty string for penalty string
     against the same loop driven by the oracle (which runs while the GPU searches);
   * write failures of the three output files injected with RLIMIT_FSIZE
     (reference: tests/testthat/test-TRAVIS-out-of-disk-space.R:37-94 mounts a full tmpfs).
@@ -108,24 +108,53 @@ def test_solve_grid_on_device(psd, tmp_path, n_contigs=24, scale=0.01, n_pen=64)
     assert stats["problems"] == n_contigs * n_pen
 
 
+_RCCL_CHILD = r"""
+import os, sys
+import numpy as np
+import torch                      # first: one HIP runtime in the process (as bench.py does)
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from peaksegdisk_amd.parallel import gather_segment_tables, pack_tables, unpack_tables
+rng = np.random.default_rng(3)
+tables = []
+for n in [0, 1, 5, 70000, 3, 0, 1234]:
+    tables.append((rng.integers(-2, 2 ** 31 - 1, n).astype(np.int32),
+                   rng.standard_normal(n) * 10.0 ** rng.integers(-300, 300, n)))
+rows, start, mean = pack_tables(tables)
+dev = torch.device("cuda", 0)
+back = [torch.from_numpy(a).to(dev).clone().cpu().numpy() for a in (rows, start, mean)]
+got = unpack_tables(*back)
+assert len(got) == len(tables)
+for (s0, m0), (s1, m1) in zip(tables, got):
+    assert np.array_equal(s0, s1) and np.array_equal(m0.view(np.uint64), m1.view(np.uint64))
+# one rank of RCCL on this GPU: the collective part of the gather
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%(port)d", rank=0, world_size=1,
+                        device_id=dev)
+out = gather_segment_tables(tables, dist, 0, always_collective=True)
+assert len(out) == 1 and len(out[0]) == len(tables)
+for (s0, m0), (s1, m1) in zip(tables, out[0]):
+    assert np.array_equal(s0, s1) and np.array_equal(m0.view(np.uint64), m1.view(np.uint64))
+dist.barrier()
+dist.destroy_process_group()
+print("rccl-one-rank ok")
+"""
+
+
 @GPU
 def test_pack_tables_through_device_tensors(psd):
     """The gather's payload (parallel.pack_tables) survives the trip numpy -> HBM -> numpy
-    bit for bit, empty and ragged tables included: what each rank's RCCL gather moves."""
-    import torch
-    from peaksegdisk_amd.parallel import pack_tables, unpack_tables
-    rng = np.random.default_rng(3)
-    tables = []
-    for n in [0, 1, 5, 70000, 3, 0, 1234]:
-        tables.append((rng.integers(-2, 2 ** 31 - 1, n).astype(np.int32),
-                       rng.standard_normal(n) * 10.0 ** rng.integers(-300, 300, n)))
-    rows, start, mean = pack_tables(tables)
-    dev = torch.device("cuda", 0)
-    back = [torch.from_numpy(a).to(dev).clone().cpu().numpy() for a in (rows, start, mean)]
-    got = unpack_tables(*back)
-    assert len(got) == len(tables)
-    for (s0, m0), (s1, m1) in zip(tables, got):
-        assert np.array_equal(s0, s1) and np.array_equal(m0.view(np.uint64), m1.view(np.uint64))
+    bit for bit, empty and ragged tables included, and the collective part of
+    gather_segment_tables runs on RCCL with one rank on this GPU.  In a child process: torch
+    ships its own HIP runtime, which must be the first one loaded (bench.py imports torch
+    before the library for the same reason)."""
+    import bench
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, "-c", _RCCL_CHILD % {"root": ROOT,
+                                                             "port": bench.free_port()}],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0 and "rccl-one-rank ok" in p.stdout, p.stdout + p.stderr
 
 
 @GPU
@@ -254,8 +283,8 @@ def _oracle_search(problem_dir, peaks_int, cli=CLI_DET):
 
 
 @GPU
-def test_sequential_search_on_a_1e6_bin_contig(psd, tmp_path, n_bins=1000000, peaks_int=500):
-    """BASELINE.json configs[2] at a tenth of its length: sequentialSearch_dir on a 1e6-bin
+def test_sequential_search_on_a_long_contig(psd, tmp_path, n_bins=500000, peaks_int=250):
+    """BASELINE.json configs[2] at a twentieth of its length: sequentialSearch_dir on a 5e5-bin
     synthetic contig.  The resident driver must ask for the models the reference's loop asks
     for: same penalty strings in the same order, same peaks, and the chosen model's files
     byte-identical to the oracle's (the oracle-driven loop runs in a thread meanwhile)."""
@@ -357,3 +386,48 @@ def test_write_failures_injected_on_the_dp_branch(psd, tmp_path, n_bins=3000):
         bg = str(tmp_path / ("fits_%s.bedGraph" % pen))
         synthetic.write_bedgraph(bg, cs, ce, cnt)
         assert run_with_file_size_limit(bg, pen, db, warm) == (0, "")
+
+
+@GPU
+def test_batch_with_duplicate_problems(psd, oracle_det, tmp_path, n_bins=2000):
+    """The same (bedGraph, penalty) pair listed twice in a batch names one pair of output
+    files: it is solved once (two writer threads on the same paths would race) and both
+    entries report the same status; a second database name is left as the first is.  The
+    directory batch dedupes the same way (one _timing.tsv, both flagged not cached)."""
+    import ctypes
+    from peaksegdisk_amd import _native, synthetic
+    cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=31)
+    d = tmp_path / "prob"
+    d.mkdir()
+    bg = str(d / "coverage.bedGraph")
+    synthetic.write_bedgraph(bg, cs, ce, cnt)
+    obg = str(tmp_path / "oracle.bedGraph")
+    shutil.copy(bg, obg)
+    link = str(tmp_path / "alias.bedGraph")  # another name of the same file
+    os.symlink(bg, link)
+    bgs = [bg, bg, link, bg]
+    pens = ["25", "25", "25", "700"]
+    dbs = [str(tmp_path / ("db%d" % k)) for k in range(4)]
+    arr = lambda xs: (ctypes.c_char_p * len(xs))(*[x.encode() for x in xs])
+    status = (ctypes.c_int * 4)(9, 9, 9, 9)
+    assert _native.lib.PeakSegFPOP_disk_batch(4, arr(bgs), arr(pens), arr(dbs), status) == 0
+    assert list(status) == [0, 0, 0, 0]
+    for pen in ("25", "700"):
+        assert oracle_det.solve(obg, pen) == 0
+        for suffix in ("_segments.bed", "_loss.tsv"):
+            assert open("%s_penalty=%s%s" % (bg, pen, suffix), "rb").read() == \
+                open("%s_penalty=%s%s" % (obg, pen, suffix), "rb").read()
+    want = os.path.getsize("%s_penalty=25.db" % obg)
+    assert [os.path.getsize(p) for p in dbs[:3]] == [want] * 3
+    # the alias was recognised: nothing was written under its own name
+    assert not os.path.exists(link + "_penalty=25_loss.tsv")
+    # directory batch: the same pair twice
+    dirs = arr([str(d), str(d)])
+    st2 = (ctypes.c_int * 2)(9, 9)
+    cached = (ctypes.c_int * 2)(9, 9)
+    assert _native.lib.PeakSegFPOP_dir_batch(2, dirs, arr(["3000", "3000"]), st2, cached) == 0
+    assert list(st2) == [0, 0] and list(cached) == [0, 0]
+    assert oracle_det.solve(obg, "3000") == 0
+    assert open(bg + "_penalty=3000_loss.tsv", "rb").read() == \
+        open(obg + "_penalty=3000_loss.tsv", "rb").read()
+    assert len(open(bg + "_penalty=3000_timing.tsv").read().split("\t")) == 3
