@@ -376,6 +376,99 @@ constexpr bool HBM_HELP = PSD_HBM_HELPER != 0;
 #else
 constexpr bool HBM_HELP = false;
 #endif
+#if defined(PSD_HELPER_WAVES) && !defined(PSD_NO_HBM_COOP)
+#define PSD_HBM_COOP 1
+/* Lists in HBM, latency build: the chain wave and its helper wave share the chunks of the
+ * three parallel phases of a step (fpop_wave.h, HOP_HBM_*): functions of adversarial data have
+ * hundreds of pieces, i.e. more than one wave's worth of lanes of work per phase. */
+PSD_COLD_DEV void helper_hbm_op(const DeviceArgs &a, int chain, int op) {
+  chain = uniform_i(chain);
+  op = uniform_i(op);
+  Mail &m = g_sm.mail[chain];
+  const int p = uniform_i(m.h_arg[0]);
+  const GlobalScratch s = global_scratch(a, p, chain);
+  if (op == HOP_HBM_COSTS) {
+    LanePiece P;
+    P.c.Linear = P.c.Log = P.c.Constant = 0.0;
+    P.mn = P.mx = P.lc = P.rc = P.om = P.mu = P.muc = P.oc2 = 0.0;
+    P.cls = CLS_STORE;
+    piece_costs_wave(global_list(a, p, uniform_i(m.h_arg[1])), uniform_i(m.h_arg[2]), s, P, 1, 2);
+  } else {
+    const GlobalList f1 = global_list(a, p, uniform_i(m.h_arg[1])).shifted(uniform_i(m.h_arg[2]));
+    const int n1 = uniform_i(m.h_arg[3]);
+    const GlobalList f2 = global_list(a, p, uniform_i(m.h_arg[4]));
+    const int n2 = uniform_i(m.h_arg[5]);
+    if (op == HOP_HBM_TABLE) {
+      env_table_second(f1, n1, f2, n2, s);
+    } else if (op == HOP_HBM_CLASSIFY) {
+      env_coop_helper(f1, n1, f2, n2, s, uniform_i(m.h_arg[6]), chain);
+    }
+  }
+}
+PSD_NOINLINE int min_less_coop_wave(GlobalList in, int n, GlobalList out, int cap, GlobalScratch s,
+                                    int data_i_out, double add_const, int chain, int p, int id) {
+  return min_less_impl<false, true>(in, n, out, cap, s, data_i_out, add_const, chain, p, id);
+}
+PSD_NOINLINE int min_more_coop_wave(GlobalList in, int n, GlobalList out, int cap, GlobalScratch s,
+                                    int data_i_out, int chain, int p, int id) {
+  return min_more_impl<false, true>(in, n, out, cap, s, data_i_out, chain, p, id);
+}
+PSD_NOINLINE int min_env_coop_wave(GlobalList f1, int n1, GlobalList f2, int n2, GlobalList out,
+                                   int cap, GlobalScratch s, int chain, int p, int id1, int off1,
+                                   int id2) {
+  return min_env_coop(f1, n1, f2, n2, out, cap, s, chain, p, id1, off1, id2);
+}
+PSD_COLD_DEV int chain_step_hbm(const DeviceArgs &a, ArenaCursor &cur,
+                                unsigned long long fn_index, int p, int chain, int t,
+                                int id_other_prev, int n_other, int id_own_prev, int n_own,
+                                int id_own_new, double pen_term, double cum_weight_prev, double w,
+                                int coverage, double cum_weight) {
+  p = uniform_i(p);
+  chain = uniform_i(chain);
+  t = uniform_i(t);
+  id_other_prev = uniform_i(id_other_prev);
+  id_own_prev = uniform_i(id_own_prev);
+  n_other = uniform_i(n_other);
+  n_own = uniform_i(n_own);
+  pen_term = uniform_d(pen_term);
+  const int cap = a.spill_cap;
+  const GlobalList other_prev = global_list(a, p, id_other_prev);
+  const GlobalList own_prev = global_list(a, p, id_own_prev);
+  const GlobalList own_new = global_list(a, p, uniform_i(id_own_new));
+  const GlobalList mlist = global_list(a, p, 4 + chain);
+  const GlobalScratch sc = global_scratch(a, p, chain);
+  int nm = 0;
+  if (chain == 0) {
+    nm = min_less_coop_wave(other_prev, n_other, mlist, cap, sc, t - 1, pen_term, chain, p,
+                            id_other_prev);
+  } else if (t >= 2) {
+    nm = min_more_coop_wave(other_prev, n_other, mlist, cap, sc, t - 1, chain, p, id_other_prev);
+  }
+  nm = uniform_i(nm);
+  if (nm < 0) return nm;
+  int n_new;
+  if (t == 1) {
+    if (chain == 0) {
+      copy_list_wave(mlist, nm, own_new);
+      n_new = nm;
+    } else {
+      copy_list_wave(own_prev, n_own, own_new);
+      n_new = n_own;
+    }
+  } else {
+    const int off1 = chain == 0 ? 0 : cap - nm;
+    n_new = uniform_i(min_env_coop_wave(mlist.shifted(off1), nm, own_prev, n_own, own_new, cap, sc,
+                                        chain, p, 4 + chain, off1, id_own_prev));
+  }
+  if (n_new < 0) return n_new;
+  wave_sync();
+  bool ok = scale_add_store_wave(a, cur, own_new, n_new, fn_index, true, uniform_d(cum_weight_prev),
+                                 uniform_d(w), (double)(-uniform_i(coverage)) * uniform_d(w),
+                                 1 / uniform_d(cum_weight));
+  wave_sync();
+  return ok ? n_new : -WERR_ARENA;
+}
+#else
 /* The same step with every list in the HBM spill area (functions that outgrew LDS): a cold,
  * out-of-line function, so that its addressing does not hold registers in the kernel's loop. */
 PSD_COLD_DEV int chain_step_hbm(const DeviceArgs &a, ArenaCursor &cur,
@@ -394,6 +487,7 @@ PSD_COLD_DEV int chain_step_hbm(const DeviceArgs &a, ArenaCursor &cur,
                            uniform_d(cum_weight_prev), uniform_d(w), uniform_i(coverage),
                            uniform_d(cum_weight));
 }
+#endif
 
 /* list ids: 2*chain + buffer for the two cost functions (chain 0 = up, 1 = down), 4 + chain
  * for the chain's min-less / min-more temporary.  Lists live in LDS (g_sm.list[id]) while
@@ -709,7 +803,7 @@ PSD_D void forward_body(const DeviceArgs &a) {
   __syncthreads();
 #ifdef PSD_HELPER_WAVES
   if (wave_id() >= 2) {
-    helper_loop(chain);
+    helper_loop(chain, a);
     return;
   }
 #endif

@@ -71,9 +71,18 @@ struct ScratchStore {
  * evaluates end costs, midpoint and the smaller-root solves.  Lane k of the helper works on
  * lane k's interval; arguments and results cross through this LDS mailbox.  HOP_BARRIER makes
  * the helper join a workgroup barrier, HOP_EXIT ends it. */
-enum { HOP_BARRIER = 1, HOP_EXIT = 2, HOP_ROOT = 3 };
+enum {
+  HOP_BARRIER = 1, HOP_EXIT = 2, HOP_ROOT = 3,
+  /* lists in HBM (functions that outgrew LDS: adversarial data): the helper takes every
+   * second chunk of 64 pieces / merged intervals of the chain wave's operation */
+  HOP_HBM_COSTS = 4,    /* first pass of min-less / min-more: the odd chunks */
+  HOP_HBM_TABLE = 5,    /* merged-interval table: the entries owned by the second function */
+  HOP_HBM_CLASSIFY = 6, /* envelope classification: the odd chunks, results left in HBM */
+};
 struct Mail {
   int seq_cmd, seq_done, op, abort;
+  int h_arg[8];   /* arguments of the HBM operations */
+  int h_progress; /* HOP_HBM_CLASSIFY: chunks the helper has finished (a flag) */
   int flags[64];
   double d_lin[64], d_log[64], d_con[64], b[64]; /* HOP_ROOT: difference piece, right end */
   double res_large[64];
@@ -287,6 +296,12 @@ struct GlobalScratch {
   PSD_M gint &cls(int i) const { return cls_[i]; }
   PSD_M gint &iv(int i) const { return iv_[i]; }
   PSD_M int iv_cap() const { return iv_cap_; }
+  /* Results of merged intervals classified by the helper wave (HOP_HBM_CLASSIFY), one slot per
+   * interval (up to 2 cap of them): the six cost arrays are contiguous in pairs (lc|rc, om|mu,
+   * muc|oc2, fpop_kernels.h global_scratch) and dead once the walk is over. */
+  PSD_M gdouble &coop_x1(int k) const { return lc_[k]; }
+  PSD_M gdouble &coop_x2(int k) const { return om_[k]; }
+  PSD_M gdouble &coop_code(int k) const { return muc_[k]; }
   PSD_M GlobalScratch uniformed() const {
     GlobalScratch r;
     r.lc_ = uniform_p(lc_);
@@ -366,9 +381,11 @@ struct LanePiece {
  * optimum (fpl:245-246,310-311 / 469-470,483-485); kept in scratch for every piece and in
  * registers for piece `lane`. */
 template <class L, class S>
-PSD_D void piece_costs_wave(const L &in, int n, const S &s, LanePiece &P) {
+PSD_D void piece_costs_wave(const L &in, int n, const S &s, LanePiece &P, int chunk0 = 0,
+                            int stride = 1) {
   const int lane = lane_id();
-  for (int base = 0; base < n; base += WAVE) {
+  /* chunks chunk0, chunk0 + stride, ...: two waves share a long function (HOP_HBM_COSTS) */
+  for (int base = chunk0 * WAVE; base < n; base += stride * WAVE) {
     int i = base + lane;
     if (i < n) {
       Coef c = load_coef(in, i);
@@ -421,10 +438,36 @@ PSD_D void piece_costs_wave(const L &in, int n, const S &s, LanePiece &P) {
 
 /* First pass of min-less: per piece the end costs and optimum (piece_costs_wave) and what the
  * walk does with the piece when it reaches it in search mode. */
+#ifdef PSD_HELPER_WAVES
+/* The costs of a function in HBM by two waves: the helper takes the odd chunks. */
 template <class L, class S>
-PSD_D void min_less_pre(const L &in, int n, const S &s, LanePiece &P) {
+PSD_D bool coop_piece_costs(const L &in, int n, const S &s, LanePiece &P, int chain, int p, int id) {
+  Mail &m = g_sm.mail[chain];
+  if (lane_id() == 0) {
+    m.h_arg[0] = p;
+    m.h_arg[1] = id;
+    m.h_arg[2] = n;
+  }
+  mail_post(chain, HOP_HBM_COSTS);
+  piece_costs_wave(in, n, s, P, 0, 2);
+  return mail_wait(chain);
+}
+#endif
+/* COOP: the function is list coop_id of spill slot coop_p and the chain's helper wave takes
+ * half of the chunks (latency build, lists in HBM). */
+template <bool COOP = false, class L, class S>
+PSD_D bool min_less_pre(const L &in, int n, const S &s, LanePiece &P, int coop_chain = 0,
+                        int coop_p = 0, int coop_id = 0) {
   const int lane = lane_id();
-  piece_costs_wave(in, n, s, P);
+  bool ok = true;
+#ifdef PSD_HELPER_WAVES
+  if (COOP) {
+    ok = coop_piece_costs(in, n, s, P, coop_chain, coop_p, coop_id);
+  } else
+#endif
+  {
+    piece_costs_wave(in, n, s, P);
+  }
   /* what the walk does with piece i when it reaches it in search mode */
   for (int base = 0; base < n; base += WAVE) {
     int i = base + lane;
@@ -461,13 +504,23 @@ PSD_D void min_less_pre(const L &in, int n, const S &s, LanePiece &P) {
     }
   }
   wave_sync();
+  return ok;
 }
 
 /* First pass of min-more, as min_less_pre. */
-template <class L, class S>
-PSD_D void min_more_pre(const L &in, int n, const S &s, LanePiece &P) {
+template <bool COOP = false, class L, class S>
+PSD_D bool min_more_pre(const L &in, int n, const S &s, LanePiece &P, int coop_chain = 0,
+                        int coop_p = 0, int coop_id = 0) {
   const int lane = lane_id();
-  piece_costs_wave(in, n, s, P);
+  bool ok = true;
+#ifdef PSD_HELPER_WAVES
+  if (COOP) {
+    ok = coop_piece_costs(in, n, s, P, coop_chain, coop_p, coop_id);
+  } else
+#endif
+  {
+    piece_costs_wave(in, n, s, P);
+  }
   for (int base = 0; base < n; base += WAVE) {
     int i = base + lane;
     if (i < n) {
@@ -496,15 +549,16 @@ PSD_D void min_more_pre(const L &in, int n, const S &s, LanePiece &P) {
     }
   }
   wave_sync();
+  return ok;
 }
 
 /* ------------------------------------------------------------------------------------- */
 /* min-less: out(x) = min_{y<=x} in(y).  All output pieces get data_i = data_i_out (the
  * driver's set_prev_seg_end) and Constant += add_const (its add(0,0,penalty/cum_weight_prev),
  * PeakSegFPOPLog.cpp:290-296). */
-template <bool SMALL, class L, class S>
+template <bool SMALL, bool COOP = false, class L, class S>
 PSD_D int min_less_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
-                        double add_const_) {
+                        double add_const_, int coop_chain = 0, int coop_p = 0, int coop_id = 0) {
   const L in = in_.uniformed(), out = out_.uniformed();
   const S s = s_.uniformed();
   const int n = uniform_i(n_), cap = uniform_i(cap_), data_i_out = uniform_i(data_i_out_);
@@ -518,7 +572,7 @@ PSD_D int min_less_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
   P.mn = P.mx = P.lc = P.rc = P.om = P.mu = P.muc = P.oc2 = 0.0;
   P.cls = CLS_STORE;
   PSD_PROF_T0();
-  min_less_pre(in, n, s, P);
+  if (!min_less_pre<COOP>(in, n, s, P, coop_chain, coop_p, coop_id)) return -WERR_HELPER;
   PSD_PROF_ADD(PROF_PRE);
   /* uniform reads of piece j: registers of lane j when the function fits one wave */
   auto cls_at = [&](int j) -> int { return small ? rdlane_i(P.cls, j) : s.cls(j); };
@@ -799,8 +853,9 @@ PSD_D int min_less_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
 /* ------------------------------------------------------------------------------------- */
 /* min-more: out(x) = min_{y>=x} in(y).  The reference builds the list with emplace_front;
  * here pieces are written downwards from out[cap-1]: the result is out[cap-n .. cap). */
-template <bool SMALL, class L, class S>
-PSD_D int min_more_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_) {
+template <bool SMALL, bool COOP = false, class L, class S>
+PSD_D int min_more_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
+                        int coop_chain = 0, int coop_p = 0, int coop_id = 0) {
   const L in = in_.uniformed(), out = out_.uniformed();
   const S s = s_.uniformed();
   const int n = uniform_i(n_), cap = uniform_i(cap_), data_i_out = uniform_i(data_i_out_);
@@ -812,7 +867,7 @@ PSD_D int min_more_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_) 
   P.mn = P.mx = P.lc = P.rc = P.om = P.mu = P.muc = P.oc2 = 0.0;
   P.cls = CLS_STORE;
   PSD_PROF_T0();
-  min_more_pre(in, n, s, P);
+  if (!min_more_pre<COOP>(in, n, s, P, coop_chain, coop_p, coop_id)) return -WERR_HELPER;
   PSD_PROF_ADD(PROF_PRE);
   auto cls_at = [&](int j) -> int { return small ? rdlane_i(P.cls, j) : s.cls(j); };
   auto mu_at = [&](int j) -> double { return small ? rdlane_d(P.mu, j) : s.mu(j); };
@@ -1649,8 +1704,10 @@ PSD_D bool bit_identical(const Coef &last, double last_prv, int last_di, const C
 }
 
 #ifdef PSD_HELPER_WAVES
+/* the helper's share of an operation on lists in HBM (fpop_kernels.h) */
+PSD_COLD_DEV void helper_hbm_op(const DeviceArgs &a, int chain, int op);
 /* Body of a helper wave: serve the main wave of `chain` until HOP_EXIT. */
-PSD_D void helper_loop(int chain) {
+PSD_D void helper_loop(int chain, const DeviceArgs &a) {
   Mail &m = g_sm.mail[chain];
   const int lane = lane_id();
   int seen = 0;
@@ -1684,6 +1741,8 @@ PSD_D void helper_loop(int chain) {
         m.res_large[lane] = root;
 
       }
+    } else if (op >= HOP_HBM_COSTS) {
+      helper_hbm_op(*a.self, chain, op);
     }
     wave_sync();
     if (lane == 0) flag_store(&m.seq_done, seen);
@@ -1983,6 +2042,295 @@ PSD_D int min_env_impl(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, i
   }
   return n_out;
 }
+
+#ifdef PSD_HELPER_WAVES
+/* ---- the envelope of two functions in HBM, by the chain wave and its helper ----------------
+ * Functions of hundreds of pieces (adversarial data) are processed in chunks of 64 merged
+ * intervals; the chunks are independent up to the compaction, which needs the number of
+ * pieces emitted so far.  The helper wave classifies the odd chunks and leaves its results
+ * (shape, first source, the two crossings, error bits) in HBM; the chain wave classifies the
+ * even chunks and compacts all chunks in order, reading the helper's results as they come.
+ * The arithmetic per interval is that of min_env_impl: same lists, bit for bit. */
+
+/* merged-interval table, the entries owned by f1 (every end of f1); returns how many ends of
+ * f1 are also ends of f2 */
+template <class L, class S>
+PSD_D int env_table_first(const L &f1, int n1, const L &f2, int n2, const S &s) {
+  const int lane = lane_id();
+  const int iv_cap = s.iv_cap();
+  int dup_before = 0;
+  for (int base = 0; base < n1; base += WAVE) {
+    int i = base + lane;
+    bool valid = i < n1;
+    int p = 0;
+    bool dup = false;
+    if (valid) {
+      double x = f1.mx(i);
+      p = rank_mx(f2, n2, x);
+      dup = p < n2 && f2.mx(p) == x;
+    }
+    unsigned long long md = ballot(dup);
+    if (valid) {
+      int k = i + p - (dup_before + popc64(md & lanes_below(lane)));
+      if (k < iv_cap) s.iv(k) = (i << 16) | p;
+    }
+    dup_before += popc64(md);
+  }
+  return dup_before;
+}
+/* ... and the entries owned by f2 (its ends that are not ends of f1) */
+template <class L, class S>
+PSD_D void env_table_second(const L &f1, int n1, const L &f2, int n2, const S &s) {
+  const int lane = lane_id();
+  const int iv_cap = s.iv_cap();
+  int dup_before = 0;
+  for (int base = 0; base < n2; base += WAVE) {
+    int j = base + lane;
+    bool valid = j < n2;
+    int q = 0;
+    bool dup = false;
+    if (valid) {
+      double x = f2.mx(j);
+      q = rank_mx(f1, n1, x);
+      dup = q < n1 && f1.mx(q) == x;
+    }
+    unsigned long long md = ballot(dup);
+    if (valid && !dup) {
+      int k = j + q - (dup_before + popc64(md & lanes_below(lane)));
+      if (k < iv_cap) s.iv(k) = (q << 16) | j;
+    }
+    dup_before += popc64(md);
+  }
+}
+
+/* one chunk of merged intervals: everything up to the candidates (the first half of the chunk
+ * loop of min_env_impl) */
+struct EnvLane {
+  Cands cd;
+  double ia, ib;
+  Coef c1, c2;
+  double prv1, prv2;
+  int di1, di2, i1, i2;
+  int err;
+};
+template <class L, class S>
+PSD_D void env_coop_load(const L &f1, int n1, const L &f2, int n2, const S &s, int k, bool valid,
+                         EnvLane &e) {
+  e.cd.n = 0;
+  e.cd.first = 0;
+  e.cd.x1 = e.cd.x2 = 0.0;
+  e.ia = e.ib = 0.0;
+  e.c1.Linear = e.c1.Log = e.c1.Constant = 0.0;
+  e.c2 = e.c1;
+  e.prv1 = e.prv2 = 0.0;
+  e.di1 = e.di2 = e.i1 = e.i2 = 0;
+  e.err = 0;
+  if (valid) {
+    int en = s.iv(k);
+    e.i1 = en >> 16;
+    e.i2 = en & 0xffff;
+    env_load_interval(f1, n1, f2, n2, e.i1, e.i2, e.c1, e.c2, e.ia, e.ib, e.err);
+    e.prv1 = f1.prv(e.i1);
+    e.di1 = f1.di(e.i1);
+    e.prv2 = f2.prv(e.i2);
+    e.di2 = f2.di(e.i2);
+  }
+}
+template <class L, class S>
+PSD_D void env_coop_classify(const L &f1, int n1, const L &f2, int n2, const S &s, int K, int base,
+                             int chain, EnvLane &e) {
+  const int k = base + lane_id();
+  const bool valid = k < K;
+  env_coop_load(f1, n1, f2, n2, s, k, valid, e);
+  bool sl = false, sr = false;
+  env_neighbour_flags(f1, f2, s, k, K, valid, valid && same_funs(e.c1, e.c2), sl, sr);
+  env_classify_lanes<false>(valid && e.err == 0, e.c1, e.c2, e.ia, e.ib, sl, sr, e.cd, chain, e.err);
+}
+
+/* the helper's share: the odd chunks, results to HBM, progress published chunk by chunk */
+template <class L, class S>
+PSD_D void env_coop_helper(const L &f1, int n1, const L &f2, int n2, const S &s, int K, int chain) {
+  Mail &m = g_sm.mail[chain];
+  int done = 0;
+  for (int base = WAVE; base < K; base += 2 * WAVE) {
+    EnvLane e;
+    env_coop_classify(f1, n1, f2, n2, s, K, base, chain, e);
+    const int k = base + lane_id();
+    if (k < K) {
+      s.coop_x1(k) = e.cd.x1;
+      s.coop_x2(k) = e.cd.x2;
+      s.coop_code(k) = (double)(e.cd.n | (e.cd.first << 2) | (e.err << 3));
+    }
+    done++;
+    wave_sync();
+    if (lane_id() == 0) flag_store(&m.h_progress, done);
+  }
+}
+
+/* the chain wave: table (with the helper), its own chunks, and the compaction of all */
+template <class L, class S>
+PSD_D int min_env_coop(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, int chain_, int p_,
+                       int id1_, int off1_, int id2_) {
+  const int chain = uniform_i(chain_);
+  const L f1 = f1_.uniformed(), f2 = f2_.uniformed(), out = out_.uniformed();
+  const S s = s_.uniformed();
+  const int n1 = uniform_i(n1_), n2 = uniform_i(n2_), cap = uniform_i(cap_);
+  const int lane = lane_id();
+  const int iv_cap = s.iv_cap();
+  Mail &m = g_sm.mail[chain];
+  PSD_PROF_T0();
+  if (lane == 0) {
+    m.h_arg[0] = p_;
+    m.h_arg[1] = id1_;
+    m.h_arg[2] = off1_;
+    m.h_arg[3] = n1;
+    m.h_arg[4] = id2_;
+    m.h_arg[5] = n2;
+  }
+  mail_post(chain, HOP_HBM_TABLE);
+  const int dup_total = env_table_first(f1, n1, f2, n2, s);
+  if (!mail_wait(chain)) return -WERR_HELPER;
+  const int K = n1 + n2 - dup_total;
+  if (K > iv_cap || n1 > SPILL_CAP_MAX || n2 > SPILL_CAP_MAX) return -WERR_OVERFLOW;
+  wave_sync();
+  PSD_PROF_ADD(PROF_TABLE);
+  if (lane == 0) {
+    m.h_arg[6] = K;
+    flag_store(&m.h_progress, 0);
+  }
+  mail_post(chain, HOP_HBM_CLASSIFY);
+
+  int n_out = 0;
+  int err = 0;
+  bool need_serial = false, overflow = false, helper_lost = false;
+  int last_id = -1;
+  for (int base = 0, chunk = 0; base < K; base += WAVE, chunk++) {
+    const int k = base + lane;
+    const bool valid = k < K;
+    EnvLane e;
+    PSD_PROF_T0();
+    if ((chunk & 1) == 0) {
+      env_coop_classify(f1, n1, f2, n2, s, K, base, chain, e);
+    } else {
+      /* the helper's chunk: wait for it, then fetch its results and the pieces they refer to */
+      const int want = (chunk + 1) / 2;
+      bool there = false;
+      for (int spin = 0; spin < MAIL_SPIN_LIMIT; spin++) {
+        if (rdlane_i(flag_load(&m.h_progress), 0) >= want) {
+          there = true;
+          break;
+        }
+        spin_pause();
+      }
+      if (!there) {
+        helper_lost = true;
+        break;
+      }
+      env_coop_load(f1, n1, f2, n2, s, k, valid, e);
+      if (valid) {
+        const int code = (int)s.coop_code(k);
+        e.cd.n = code & 3;
+        e.cd.first = (code >> 2) & 1;
+        e.err |= code >> 3;
+        e.cd.x1 = s.coop_x1(k);
+        e.cd.x2 = s.coop_x2(k);
+      }
+    }
+    err = e.err;
+    PSD_PROF_ADD(PROF_CLASSIFY);
+    /* ---- compaction: as in min_env_impl ---- */
+    const Cands &cd = e.cd;
+    const int src0 = cd.first, src1 = cd.first ^ 1;
+    Coef fc = src0 ? e.c2 : e.c1;
+    double fprv = src0 ? e.prv2 : e.prv1;
+    int fdi = src0 ? e.di2 : e.di1;
+    int lsrc = cd.n == 2 ? src1 : src0;
+    const double hi0 = cd.n == 1 ? e.ib : cd.x1;
+    const double hi1 = cd.n == 2 ? e.ib : cd.x2;
+    bool has = valid && cd.n > 0;
+    unsigned long long m_has = ballot(has);
+    unsigned long long m_err = ballot(err != 0);
+    if (m_err) {
+      int eb = 0;
+      for (int l = 0; l < WAVE; l++) eb |= shfl_i(err, l);
+      err = eb;
+      break;
+    }
+    unsigned long long lb = lanes_below(lane);
+    unsigned long long below = m_has & lb;
+    const int my_last_id = (lsrc << 20) | (lsrc ? e.i2 : e.i1);
+    int pid = shfl_i(my_last_id, below ? msb64(below) : 0);
+    if (!below) pid = last_id;
+    const bool have_pred = pid >= 0;
+    Coef pc = {0.0, 0.0, 0.0};
+    double pprv = 0.0;
+    int pdi = 0;
+    if (has && have_pred) {
+      const L &pl = (pid >> 20) ? f2 : f1;
+      const int pi = pid & 0xfffff;
+      pc = load_coef(pl, pi);
+      pprv = pl.prv(pi);
+      pdi = pl.di(pi);
+    }
+    bool head0 = true;
+    bool fuzzy = false;
+    if (has && have_pred) {
+      bool co = coalesces(pc, pprv, pdi, fc, fprv, fdi);
+      bool bi = bit_identical(pc, pprv, pdi, fc, fprv, fdi);
+      head0 = !co;
+      fuzzy = co && !bi;
+    }
+    if (ballot(fuzzy)) {
+      need_serial = true;
+      break;
+    }
+    int heads = has ? ((head0 ? 1 : 0) + (cd.n - 1)) : 0;
+    unsigned long long hb0 = ballot((heads & 1) != 0);
+    unsigned long long hb1 = ballot((heads & 2) != 0);
+    int heads_before = popc64(hb0 & lb) + 2 * popc64(hb1 & lb);
+    int heads_total = popc64(hb0) + 2 * popc64(hb1);
+    if (n_out + heads_total > cap) {
+      overflow = true;
+      break;
+    }
+    int slot = n_out + heads_before - (head0 ? 0 : 1);
+    if (has) {
+      if (head0) store_piece(out, slot, fc, e.ia, hi0, fdi, fprv);
+      if (cd.n >= 2) {
+        Coef c = src1 ? e.c2 : e.c1;
+        store_piece(out, slot + 1, c, cd.x1, hi1, src1 ? e.di2 : e.di1, src1 ? e.prv2 : e.prv1);
+      }
+      if (cd.n >= 3) store_piece(out, slot + 2, fc, cd.x2, e.ib, fdi, fprv);
+    }
+    wave_sync();
+    {
+      unsigned long long m_head0 = ballot(has && head0);
+      if (has && !head0) {
+        unsigned long long above = m_has & ~lb & ~(1ull << lane);
+        bool next_is_head = true;
+        if (above) next_is_head = ((m_head0 >> ctz64(above)) & 1ull) != 0;
+        if (cd.n >= 2 || next_is_head) out.mx(slot) = hi0;
+      }
+    }
+    wave_sync();
+    n_out += heads_total;
+    if (m_has) last_id = rdlane_i(my_last_id, msb64(m_has));
+    PSD_PROF_ADD(PROF_COMPACT);
+  }
+  /* the helper finishes its chunks whatever happened here (they are bounded work) */
+  if (!mail_wait(chain) || helper_lost) return -WERR_HELPER;
+  if (err) return -err;
+  if (overflow) return -WERR_OVERFLOW;
+#ifdef PSD_FORCE_SERIAL_ENV
+  need_serial = true;
+#endif
+  if (need_serial) {
+    if (lane == 0) g_sm.serial[wave_id()]++;
+    n_out = min_env_serial(f1, n1, f2, n2, out, cap, s, K);
+  }
+  return n_out;
+}
+#endif /* PSD_HELPER_WAVES */
 
 /* The three operations, out of line (see the head of this file).  The kernel inlines the
  * LDS instantiations into its loop -- one copy each, ~40 KB of code, and no call overhead

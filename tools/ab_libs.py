@@ -19,6 +19,8 @@ ap.add_argument("--bins", type=int, default=100000)
 ap.add_argument("--contigs", type=int, default=1)
 ap.add_argument("--unequal", action="store_true",
                 help="contig lengths log-uniform in [bins/100, bins] (the config-4 shape)")
+ap.add_argument("--increasing", action="store_true",
+                help="config 5: one contig of counts 1..bins at penalty 100 (lists in HBM)")
 ap.add_argument("libs", nargs="+")
 args = ap.parse_args()
 contigs = []
@@ -31,6 +33,12 @@ for k in range(args.contigs):
     contigs.append((cnt, (ce - cs).astype(np.int32)))
 pens = synthetic.penalty_grid(64)
 problems = [(k, float(p)) for k in range(args.contigs) for p in pens]
+if args.increasing:
+    cs, ce, cnt = synthetic.increasing_coverage(args.bins)
+    contigs = [(cnt, (ce - cs).astype(np.int32))]
+    lens = [args.bins]
+    pens = ["100"]
+    problems = [(0, 100.0)]
 
 
 def bind(path):
@@ -56,7 +64,7 @@ for name in args.libs:
     lib = bind(name)
     ps = ProblemSet(contigs, problems, lib=lib)
     ps.solve()
-    f = [ps.solve()[0] for _ in range(1 if args.unequal else 2)]
+    f = [ps.solve()[0] for _ in range(1 if (args.unequal or args.increasing) else 2)]
     print(name, getattr(ps, "kernel_build", ""), "forward ms", min(f), "=> bins/s",
           int(np.sum(lens)) * len(pens) / (min(f) / 1e3), flush=True)
     ps.close()
