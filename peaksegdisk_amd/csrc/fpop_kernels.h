@@ -399,7 +399,13 @@ PSD_COLD_DEV void helper_hbm_op(const DeviceArgs &a, int chain, int op) {
     const GlobalList f2 = global_list(a, p, uniform_i(m.h_arg[4]));
     const int n2 = uniform_i(m.h_arg[5]);
     if (op == HOP_HBM_TABLE) {
-      env_table_second(f1, n1, f2, n2, s);
+      const ldouble *staged = nullptr;
+      if (n1 + n2 <= COOP_STAGE_DOUBLES) { /* the ends of f1 behind the chain wave's copy of f2's */
+        ldouble *dst = coop_stage(chain) + n2;
+        coop_stage_ends(f1, n1, dst);
+        staged = dst;
+      }
+      env_table_second(f1, n1, f2, n2, s, staged);
     } else if (op == HOP_HBM_CLASSIFY) {
       env_coop_helper(f1, n1, f2, n2, s, uniform_i(m.h_arg[6]), chain);
     }

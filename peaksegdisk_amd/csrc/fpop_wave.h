@@ -2052,10 +2052,37 @@ PSD_D int min_env_impl(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, i
  * even chunks and compacts all chunks in order, reading the helper's results as they come.
  * The arithmetic per interval is that of min_env_impl: same lists, bit for bit. */
 
+/* With the lists in HBM the LDS-resident lists are dead storage: the ends (max_log_mean) of
+ * the function a wave ranks against are staged there, so that the binary search of every lane
+ * (ten to fifteen dependent reads) runs at LDS instead of L2 latency.  Chain c owns the storage
+ * of lists 3c..3c+2, the chain wave the first part (the ends of f2), its helper the rest (the
+ * ends of f1); functions too long for it are searched in HBM as before. */
+constexpr int COOP_STAGE_DOUBLES = 3 * (int)(sizeof(ListStore) / sizeof(double));
+PSD_D ldouble *coop_stage(int chain) { return (ldouble *)&g_sm.list[3 * chain]; }
+template <class L>
+PSD_D void coop_stage_ends(const L &f, int n, ldouble *dst) {
+  for (int i = lane_id(); i < n; i += WAVE) dst[i] = f.mx(i);
+  wave_sync();
+}
+/* number of entries of the sorted array a[0..n) below x */
+PSD_D int rank_staged(const ldouble *a, int n, double x) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (a[mid] < x) {
+      lo = mid + 1;
+    } else {
+      hi = mid;
+    }
+  }
+  return lo;
+}
+
 /* merged-interval table, the entries owned by f1 (every end of f1); returns how many ends of
- * f1 are also ends of f2 */
+ * f1 are also ends of f2.  staged: the ends of f2 in LDS (or nullptr) */
 template <class L, class S>
-PSD_D int env_table_first(const L &f1, int n1, const L &f2, int n2, const S &s) {
+PSD_D int env_table_first(const L &f1, int n1, const L &f2, int n2, const S &s,
+                          const ldouble *staged) {
   const int lane = lane_id();
   const int iv_cap = s.iv_cap();
   int dup_before = 0;
@@ -2066,8 +2093,13 @@ PSD_D int env_table_first(const L &f1, int n1, const L &f2, int n2, const S &s) 
     bool dup = false;
     if (valid) {
       double x = f1.mx(i);
-      p = rank_mx(f2, n2, x);
-      dup = p < n2 && f2.mx(p) == x;
+      if (staged) {
+        p = rank_staged(staged, n2, x);
+        dup = p < n2 && staged[p] == x;
+      } else {
+        p = rank_mx(f2, n2, x);
+        dup = p < n2 && f2.mx(p) == x;
+      }
     }
     unsigned long long md = ballot(dup);
     if (valid) {
@@ -2078,9 +2110,10 @@ PSD_D int env_table_first(const L &f1, int n1, const L &f2, int n2, const S &s) 
   }
   return dup_before;
 }
-/* ... and the entries owned by f2 (its ends that are not ends of f1) */
+/* ... and the entries owned by f2 (its ends that are not ends of f1); staged: the ends of f1 */
 template <class L, class S>
-PSD_D void env_table_second(const L &f1, int n1, const L &f2, int n2, const S &s) {
+PSD_D void env_table_second(const L &f1, int n1, const L &f2, int n2, const S &s,
+                            const ldouble *staged) {
   const int lane = lane_id();
   const int iv_cap = s.iv_cap();
   int dup_before = 0;
@@ -2091,8 +2124,13 @@ PSD_D void env_table_second(const L &f1, int n1, const L &f2, int n2, const S &s
     bool dup = false;
     if (valid) {
       double x = f2.mx(j);
-      q = rank_mx(f1, n1, x);
-      dup = q < n1 && f1.mx(q) == x;
+      if (staged) {
+        q = rank_staged(staged, n1, x);
+        dup = q < n1 && staged[q] == x;
+      } else {
+        q = rank_mx(f1, n1, x);
+        dup = q < n1 && f1.mx(q) == x;
+      }
     }
     unsigned long long md = ballot(dup);
     if (valid && !dup) {
@@ -2147,12 +2185,25 @@ PSD_D void env_coop_classify(const L &f1, int n1, const L &f2, int n2, const S &
   env_classify_lanes<false>(valid && e.err == 0, e.c1, e.c2, e.ia, e.ib, sl, sr, e.cd, chain, e.err);
 }
 
-/* the helper's share: the odd chunks, results to HBM, progress published chunk by chunk */
+/* Which chunks of merged intervals the helper classifies: three of every five.  The chain wave
+ * also compacts every chunk (and re-reads the pieces of the helper's chunks for that), so an
+ * even split leaves the helper idle a third of the time. */
+PSD_D bool coop_helper_owns(int chunk) {
+  const int r = chunk % 5;
+  return r == 1 || r == 3 || r == 4;
+}
+/* helper-owned chunks among chunks 0..chunk */
+PSD_D int coop_helper_chunks_upto(int chunk) {
+  const int r = chunk % 5;
+  return (chunk / 5) * 3 + (r >= 1 ? 1 : 0) + (r >= 3 ? 1 : 0) + (r >= 4 ? 1 : 0);
+}
+/* the helper's share: its chunks, results to HBM, progress published chunk by chunk */
 template <class L, class S>
 PSD_D void env_coop_helper(const L &f1, int n1, const L &f2, int n2, const S &s, int K, int chain) {
   Mail &m = g_sm.mail[chain];
   int done = 0;
-  for (int base = WAVE; base < K; base += 2 * WAVE) {
+  for (int base = 0, chunk = 0; base < K; base += WAVE, chunk++) {
+    if (!coop_helper_owns(chunk)) continue;
     EnvLane e;
     env_coop_classify(f1, n1, f2, n2, s, K, base, chain, e);
     const int k = base + lane_id();
@@ -2188,7 +2239,13 @@ PSD_D int min_env_coop(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, i
     m.h_arg[5] = n2;
   }
   mail_post(chain, HOP_HBM_TABLE);
-  const int dup_total = env_table_first(f1, n1, f2, n2, s);
+  const ldouble *staged = nullptr;
+  if (n1 + n2 <= COOP_STAGE_DOUBLES) { /* (the helper makes the same test) */
+    ldouble *dst = coop_stage(chain);
+    coop_stage_ends(f2, n2, dst);
+    staged = dst;
+  }
+  const int dup_total = env_table_first(f1, n1, f2, n2, s, staged);
   if (!mail_wait(chain)) return -WERR_HELPER;
   const int K = n1 + n2 - dup_total;
   if (K > iv_cap || n1 > SPILL_CAP_MAX || n2 > SPILL_CAP_MAX) return -WERR_OVERFLOW;
@@ -2209,11 +2266,11 @@ PSD_D int min_env_coop(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, i
     const bool valid = k < K;
     EnvLane e;
     PSD_PROF_T0();
-    if ((chunk & 1) == 0) {
+    if (!coop_helper_owns(chunk)) {
       env_coop_classify(f1, n1, f2, n2, s, K, base, chain, e);
     } else {
       /* the helper's chunk: wait for it, then fetch its results and the pieces they refer to */
-      const int want = (chunk + 1) / 2;
+      const int want = coop_helper_chunks_upto(chunk);
       bool there = false;
       for (int spin = 0; spin < MAIL_SPIN_LIMIT; spin++) {
         if (rdlane_i(flag_load(&m.h_progress), 0) >= want) {

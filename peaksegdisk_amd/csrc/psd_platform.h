@@ -40,7 +40,9 @@
 typedef double gdouble;
 typedef int gint;
 typedef unsigned long long gull;
+typedef double ldouble; /* a double in LDS reached through a computed pointer */
 #else
+typedef double __attribute__((address_space(3))) ldouble;
 typedef double __attribute__((address_space(1))) gdouble;
 typedef int __attribute__((address_space(1))) gint;
 typedef unsigned long long __attribute__((address_space(1))) gull;
