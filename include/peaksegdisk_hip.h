@@ -44,6 +44,9 @@ extern "C" {
  * PEAKSEG_HIP_SPILL_CAP / _SPILL_SLOTS  capacity (pieces per list, at most 32767) and initial
  *                               number of slots of the HBM spill pool for functions that outgrow LDS
  * PEAKSEG_HIP_CHECKPOINT=K / PEAKSEG_HIP_NO_CHECKPOINT=1  force / forbid the checkpointed store
+ * PEAKSEG_HIP_CKPT_OVERFLOW     initial size (pieces) of the pool that holds checkpoints of functions
+ *                               too long for a checkpoint slot (adversarial data)
+ * PEAKSEG_HIP_NO_PARK=1         rerun a set that ran out of arena instead of resuming its problems
  * PEAKSEG_HIP_VARIANT=lat|thr   force a build of the forward kernel
  * PEAKSEG_HIP_TIMING=1          phase timings of the file-level calls on stderr */
 
@@ -189,6 +192,13 @@ int peakseg_hip_problem_set_checkpoint_interval(psd_problem_set *set);
 
 /* bytes of the arena the last solve handed out (whole chunks) */
 unsigned long long peakseg_hip_problem_set_arena_bytes_used(psd_problem_set *set);
+
+/* How the last solve went: kernel launches (1 unless a store had to grow: the arena grows by a
+ * segment and the problems it had parked are resumed, finished problems are never repeated) and
+ * the data points its launches worked through (the sum of the problems' lengths when nothing
+ * was repeated). */
+int peakseg_hip_problem_set_solve_stats(psd_problem_set *set, int *launches,
+                                        unsigned long long *steps_run);
 
 /* Change one problem's penalty in place (the contig stays resident, the arena is reused by the
  * next solve): what the penalty search does between its dynamic programs.  0 or -1. */

@@ -118,6 +118,9 @@ def declare(lib):
     lib.peakseg_hip_problem_set_checkpoint_interval.restype = c.c_int
     lib.peakseg_hip_paste_double.argtypes = [c.c_double, c.c_char_p, c.c_size_t]
     lib.peakseg_hip_paste_double.restype = c.c_int
+    lib.peakseg_hip_problem_set_solve_stats.argtypes = [
+        c.c_void_p, c.POINTER(c.c_int), c.POINTER(c.c_ulonglong)]
+    lib.peakseg_hip_problem_set_solve_stats.restype = c.c_int
     return lib
 
 
@@ -133,6 +136,7 @@ EXPORTED_SYMBOLS = [
     "PeakSegFPOP_sequential_search_batch",
     "peakseg_hip_problem_set_set_penalty", "peakseg_hip_problem_set_arena_bytes_used",
     "peakseg_hip_paste_double", "peakseg_hip_problem_set_checkpoint_interval",
+    "peakseg_hip_problem_set_solve_stats",
 ]
 
 if not os.path.exists(LIB_PATH):

@@ -646,11 +646,13 @@ PSD_COLD_DEV int take_spill_slot(const DeviceArgs &a, int chain) {
 
 /* ---- checkpointed store ----------------------------------------
  * Checkpoint slot k of a problem holds the two live functions after data point (k+1) K: per
- * slot 4 + 12 cap doubles {cum_weight, -, overflow offsets of the two chains (bit patterns),
- * then per chain Lin, Log, Con, mn, mx, prv} and 2 + 2 cap ints {n_up, n_down, then per chain
- * data_i}.  A function with more than cap pieces lives in the overflow pool (6 n doubles from
+ * slot 6 + 12 cap doubles {cum_weight, -, overflow offsets of the two chains, interval totals
+ * of the two chains (bit patterns), then per chain Lin, Log, Con, mn, mx, prv} and 8 + 2 cap
+ * ints {n_up, n_down, data point, max intervals of the two chains, spill steps, -, -, then per
+ * chain data_i}.  The full store keeps ONE such slot per problem: the park slot, written when
+ * the arena runs out (park_state) and read back when the problem is resumed.  A function with more than cap pieces lives in the overflow pool (6 n doubles from
  * 6 off, n ints from off) and the slot only holds its offset. */
-constexpr int CKPT_HDR_F64 = 4, CKPT_HDR_I32 = 2;
+constexpr int CKPT_HDR_F64 = 6, CKPT_HDR_I32 = 8;
 PSD_D size_t ckpt_f64_at(const DeviceArgs &a, long long slot) {
   return (size_t)slot * (CKPT_HDR_F64 + 12 * (size_t)a.ckpt_cap);
 }
@@ -759,6 +761,29 @@ PSD_COLD_DEV double ckpt_cum_weight(const DeviceArgs &a, int p, int k) {
   const long long slot = a.prob_ckpt_off[uniform_i(p)] + uniform_i(k);
   return a.ckpt_f64[ckpt_f64_at(a, slot)];
 }
+/* what a parked problem needs besides its two functions (slot 0 of the problem) */
+PSD_COLD_DEV void park_counters_save(const DeviceArgs &a, int p, int chain, int t,
+                                     unsigned long long total_intervals, int max_intervals,
+                                     int spill_steps) {
+  const long long slot = a.prob_ckpt_off[uniform_i(p)];
+  chain = uniform_i(chain);
+  if (lane_id() == 0) {
+    a.ckpt_f64[ckpt_f64_at(a, slot) + 4 + (size_t)chain] = psd_u2d(total_intervals);
+    a.ckpt_i32[ckpt_i32_at(a, slot) + 3 + (size_t)chain] = max_intervals;
+    if (chain == 1) {
+      a.ckpt_i32[ckpt_i32_at(a, slot) + 2] = t;
+      a.ckpt_i32[ckpt_i32_at(a, slot) + 5] = spill_steps;
+    }
+  }
+}
+PSD_COLD_DEV unsigned long long park_total_intervals(const DeviceArgs &a, int p, int chain) {
+  const long long slot = a.prob_ckpt_off[uniform_i(p)];
+  return psd_d2u(uniform_d(a.ckpt_f64[ckpt_f64_at(a, slot) + 4 + (size_t)uniform_i(chain)]));
+}
+PSD_COLD_DEV int park_int(const DeviceArgs &a, int p, int which) {
+  const long long slot = a.prob_ckpt_off[uniform_i(p)];
+  return uniform_i(a.ckpt_i32[ckpt_i32_at(a, slot) + (size_t)uniform_i(which)]);
+}
 
 /* PSD_KERNEL_WAVES_PER_EU (throughput build): keep the kernel's own register use within the
  * budget of that many waves per SIMD, as the out-of-line operations already are */
@@ -840,10 +865,12 @@ PSD_D void forward_body(const DeviceArgs &a) {
   int spill_slot = -1; /* this problem's slot of the HBM spill pool, taken on first overflow */
   int t = 0;
   int t_lo = 0, t_hi = N; /* data points of this pass */
+  int t_first = 0;        /* where this pass starts: t_lo, or the data point a parked problem resumes at */
   int t_origin = 0;       /* fn_ref index of data point t: t - t_origin */
   int next_ckpt = K > 0 ? K : -1;
   bool forward = true;    /* the first pass */
   int step_reached = 0;
+  int parked = 0;
   BtState bt;
   bt.best_log_mean = bt.prev_log_mean = 0.0;
   bt.prev_seg_end = -1;
@@ -858,11 +885,43 @@ PSD_D void forward_body(const DeviceArgs &a) {
 #ifdef PSD_PROFILE
   long long t_begin = cycle_now();
 #endif
+  bool resumed_abort = false;
+  if (!CKPT && a.prob_resume != nullptr) {
+    /* A problem parked by an earlier launch (the arena had run out): its two functions, the
+     * cumulated weight and its counters come back from the park slot and the pass goes on at
+     * the data point it had reached. */
+    const int t_resume = uniform_i(a.prob_resume[p]);
+    if (t_resume > 0) {
+      device_fence();
+      in_hbm = uniform_i(ckpt_count(*a.self, p, 0, 0)) > LDS_CAP ||
+               uniform_i(ckpt_count(*a.self, p, 0, 1)) > LDS_CAP;
+      if (in_hbm) {
+        spill_slot = uniform_i(take_spill_slot(*a.self, chain));
+        if (spill_slot < 0) {
+          status = PST_SPILL_FULL;
+          resumed_abort = true;
+        }
+      }
+      if (!resumed_abort) {
+        const int n_ck = uniform_i(ckpt_load(*a.self, p, 0, chain, 2 * chain, in_hbm ? 1 : 0,
+                                             spill_slot));
+        if (lane == 0) g_sm.n[2 * chain] = n_ck;
+        cum_weight_i = uniform_d(ckpt_cum_weight(*a.self, p, 0));
+        cum_weight_prev_i = cum_weight_i;
+        total_intervals = park_total_intervals(*a.self, p, chain);
+        max_intervals = park_int(*a.self, p, 3 + chain);
+        spill_steps = park_int(*a.self, p, 5);
+        t_first = t_resume; /* (t_lo stays 0: the decoding goes back to the first data point) */
+        block_sync(chain); /* both functions are in place before either chain reads the other's */
+      }
+    }
+  }
   for (;;) { /* passes */
-  for (t = t_lo; t < t_hi; t++) {
+  if (resumed_abort) break;
+  for (t = t_first; t < t_hi; t++) {
     PSD_PROF_T0();
     if (!CKPT) cur.store = 1; /* known to the compiler even after a cold call returned the cursor */
-    if ((t & 63) == 0 || (CKPT && t == t_lo)) { /* coalesced read of the next 64 data points */
+    if ((t & 63) == 0 || t == t_first) { /* coalesced read of the next 64 data points */
       int tt = (t & ~63) + lane;
       cnt_reg = tt < N ? count[tt] : 0;
       wt_reg = tt < N ? weight[tt] : 0;
@@ -968,7 +1027,29 @@ PSD_D void forward_body(const DeviceArgs &a) {
       }
       break;
     }
-    if (status != 0) break;
+    if (status != 0) {
+      if (!CKPT && status == PST_ARENA_FULL && a.prob_resume != nullptr && t > 0) {
+        /* Out of arena: park.  The functions of data point t-1 (this step's inputs, untouched)
+         * go to the park slot; the host adds a segment and resumes the problem at t.  Both
+         * waves see the status, so both come here.  (Functions too long for a slot need the
+         * overflow pool; without room there the problem is simply rerun from the start.) */
+        const int n_up = uniform_i(g_sm.n[b]), n_down = uniform_i(g_sm.n[2 + b]);
+        unsigned long long ovf = 0;
+        bool can_park = true;
+        if (n_up > a.ckpt_cap || n_down > a.ckpt_cap) {
+          ovf = psd_d2u(uniform_d(psd_u2d(ckpt_take_overflow(*a.self, chain, n_up, n_down))));
+          if (ovf == ~0ull) can_park = false;
+          if (can_park && chain == 1 && n_up > a.ckpt_cap) ovf += (unsigned long long)n_up;
+        }
+        if (can_park) {
+          ckpt_save(*a.self, p, 0, chain, 2 * chain + b, chain == 0 ? n_up : n_down, cum_weight_i,
+                    in_hbm ? 1 : 0, spill_slot, ovf);
+          park_counters_save(*a.self, p, chain, t, total_intervals, max_intervals, spill_steps);
+          parked = 1;
+        }
+      }
+      break;
+    }
     if (!CKPT || forward) {
       total_intervals += (unsigned long long)n_new;
       if (max_intervals < n_new) max_intervals = n_new;
@@ -1043,6 +1124,7 @@ PSD_D void forward_body(const DeviceArgs &a) {
   t_origin = c * K;
   t_lo = c == 0 ? 0 : c * K + 1;
   t_hi = (c + 1) * K + 1 < N ? (c + 1) * K + 1 : N;
+  t_first = t_lo;
   cur.base = ((unsigned long long)p * 2ull + (unsigned long long)chain) * a.ckpt_region;
   cur.used = 0;
   cur.room = (int)a.ckpt_region;
@@ -1095,6 +1177,7 @@ PSD_D void forward_body(const DeviceArgs &a) {
     r.n_serial_env = g_sm.serial[0] + g_sm.serial[1];
     r.step_reached = step_reached;
     r.spill_steps = spill_steps;
+    r.parked = parked;
     if (lane == 0) a.result[p] = r;
   }
 }

@@ -45,6 +45,8 @@ struct ProbResult {
   int n_serial_env;       /* min-envelope calls that needed the sequential replay */
   int step_reached;
   int spill_steps;        /* data points processed with the lists in the HBM spill area */
+  int parked;             /* PST_ARENA_FULL: the state before data point step_reached is in the
+                             problem's park slot, the problem can be resumed there */
 };
 
 struct DeviceArgs {
@@ -68,11 +70,20 @@ struct DeviceArgs {
   const double *contig_max_log_mean;
   const int *count;  /* 4th bedGraph column */
   const int *weight; /* chromEnd - chromStart */
-  /* arena: the in-HBM cost-function store */
+  /* arena: the in-HBM cost-function store.  Three arrays at fixed addresses for the life of the
+   * set: the host reserves address space for the largest arena the device could hold and maps
+   * memory behind it as needed (HIP virtual memory management), so that a solve which runs out
+   * of room can be continued after MORE memory has been mapped at the arena's end -- nothing
+   * is copied, no record moves, the kernel's addressing never changes.  The kernel parks the
+   * problems that ran out (their two live functions go to the problem's park slot) and the
+   * host relaunches those problems only, from the data point they had reached. */
   double *ar_mx;
   double *ar_prv;
   int *ar_di;
-  unsigned long long ar_cap; /* pieces */
+  unsigned long long ar_cap; /* pieces (mapped) */
+  /* per problem: the data point to resume at after a regrowth (0: from the start); nullptr when
+   * the set has no park slots */
+  const int *prob_resume;
   int ar_chunk_log2;
   unsigned long long *ar_next_chunk;
   unsigned long long *fn_ref;

@@ -291,6 +291,27 @@ struct psd_problem_set {
   bool throughput = false; /* which kernel build the last solve used */
   int n_lat_mixed = 0;     /* mixed launch: this many (longest) problems ran on the latency build */
   std::vector<int> order;  /* problems, longest contig first */
+  bool can_park = false;   /* the set has a park slot per problem (full store) */
+  /* the arena's three arrays: address space reserved once (vmm), memory mapped behind it in
+   * steps; or, without virtual memory management, plain allocations that growing copies */
+  bool arena_vmm = false;
+  unsigned long long arena_reserved = 0; /* pieces of address space per array */
+  unsigned long long arena_block = 0;    /* pieces per mapping: every mapping of a range has the
+                                            size of the first one (the runtime refuses
+                                            hipMemSetAccess on ranges mapped in unequal sizes) */
+  struct ArenaMap {
+    int array; /* 0 mx, 1 prv, 2 di */
+    size_t offset, bytes;
+#ifndef PSD_EMU
+    hipMemGenericAllocationHandle_t handle;
+#endif
+  };
+  std::vector<ArenaMap> arena_maps;
+  int *d_resume = nullptr; /* device copy of resume_t */
+  int *d_order_sub = nullptr; /* launch order of a relaunch: the unfinished problems */
+  std::vector<int> resume_t;  /* per problem: data point to resume at (0: from the start) */
+  int launches = 0;                     /* kernel launches of the last solve */
+  unsigned long long steps_run = 0;     /* data points the last solve's launches worked through */
   hipStream_t stream2 = nullptr;
   hipEvent_t ev2 = nullptr;
   int *started = nullptr; /* pinned host word: latency-build workgroups of a mixed launch */
@@ -326,22 +347,13 @@ int dev_upload(psd_problem_set *s, const T **p, const std::vector<T> &v) {
   return 0;
 }
 
-void free_arena(psd_problem_set *s) {
-  void *ptrs[3] = {s->d.ar_mx, s->d.ar_prv, s->d.ar_di};
-  for (void *q : ptrs) {
-    if (!q) continue;
-    for (size_t i = 0; i < s->allocs.size(); i++) {
-      if (s->allocs[i] == q) {
-        s->allocs.erase(s->allocs.begin() + (long)i);
-        break;
-      }
+void forget_alloc(psd_problem_set *s, void *q) {
+  for (size_t i = 0; i < s->allocs.size(); i++) {
+    if (s->allocs[i] == q) {
+      s->allocs.erase(s->allocs.begin() + (long)i);
+      break;
     }
-    (void)hipFree(q);
   }
-  s->bytes -= s->d.ar_cap * 20ull;
-  s->d.ar_mx = s->d.ar_prv = nullptr;
-  s->d.ar_di = nullptr;
-  s->d.ar_cap = 0;
 }
 
 unsigned long long env_bytes(const char *name) {
@@ -374,20 +386,193 @@ unsigned long long arena_fit(psd_problem_set *s) {
   return fit;
 }
 
+
+/* release the arena: mappings and address space (vmm) or the allocations */
+void free_arena(psd_problem_set *s) {
+#ifndef PSD_EMU
+  if (s->arena_vmm) {
+    void *base[3] = {s->d.ar_mx, s->d.ar_prv, s->d.ar_di};
+    const size_t esz[3] = {8, 8, 4};
+    for (auto &m : s->arena_maps) {
+      (void)hipMemUnmap((char *)base[m.array] + m.offset, m.bytes);
+      (void)hipMemRelease(m.handle);
+    }
+    s->arena_maps.clear();
+    for (int q = 0; q < 3; q++)
+      if (base[q]) (void)hipMemAddressFree(base[q], (size_t)s->arena_reserved * esz[q]);
+    s->arena_vmm = false;
+    s->arena_reserved = 0;
+  } else
+#endif
+  {
+    void *ptrs[3] = {s->d.ar_mx, s->d.ar_prv, s->d.ar_di};
+    for (void *q : ptrs) {
+      if (!q) continue;
+      forget_alloc(s, q);
+      (void)hipFree(q);
+    }
+  }
+  s->bytes -= s->d.ar_cap * 20ull;
+  s->d.ar_mx = s->d.ar_prv = nullptr;
+  s->d.ar_di = nullptr;
+  s->d.ar_cap = 0;
+}
+
+#ifndef PSD_EMU
+/* Reserve address space for the largest arena this device could ever hold (its whole memory),
+ * for each of the three arrays.  False when virtual memory management is not available. */
+bool arena_reserve(psd_problem_set *s) {
+  if (getenv("PEAKSEG_HIP_NO_VMM")) return false;
+  int vmm = 0;
+  if (hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, s->device) !=
+          hipSuccess ||
+      !vmm)
+    return false;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return false;
+  unsigned long long pieces = (unsigned long long)total_b / 20ull;
+  pieces = (pieces + 0xfffffull) & ~0xfffffull; /* whole mebi-pieces: any granularity divides it */
+  void *base[3] = {nullptr, nullptr, nullptr};
+  const size_t esz[3] = {8, 8, 4};
+  for (int q = 0; q < 3; q++) {
+    if (hipMemAddressReserve(&base[q], (size_t)pieces * esz[q], (size_t)2 << 20, nullptr, 0) != hipSuccess) {
+      for (int r = 0; r < q; r++) (void)hipMemAddressFree(base[r], (size_t)pieces * esz[r]);
+      (void)hipGetLastError();
+      return false;
+    }
+  }
+  s->d.ar_mx = (double *)base[0];
+  s->d.ar_prv = (double *)base[1];
+  s->d.ar_di = (int *)base[2];
+  s->arena_reserved = pieces;
+  s->arena_vmm = true;
+  return true;
+}
+
+/* map memory behind pieces [from, to) of the three arrays */
+int arena_map_more(psd_problem_set *s, unsigned long long from, unsigned long long to) {
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = s->device;
+  hipMemAccessDesc acc = {};
+  acc.location.type = hipMemLocationTypeDevice;
+  acc.location.id = s->device;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  void *base[3] = {s->d.ar_mx, s->d.ar_prv, s->d.ar_di};
+  const size_t esz[3] = {8, 8, 4};
+  const size_t first_new = s->arena_maps.size();
+  for (int q = 0; q < 3; q++) {
+    psd_problem_set::ArenaMap m;
+    m.array = q;
+    m.offset = (size_t)from * esz[q];
+    m.bytes = (size_t)(to - from) * esz[q];
+    const char *what = "hipMemCreate";
+    hipError_t e = hipMemCreate(&m.handle, m.bytes, &prop, 0);
+    if (e == hipSuccess) {
+      what = "hipMemMap";
+      e = hipMemMap((char *)base[q] + m.offset, m.bytes, 0, m.handle, 0);
+      if (e == hipSuccess) {
+        what = "hipMemSetAccess";
+        e = hipMemSetAccess((char *)base[q] + m.offset, m.bytes, &acc, 1);
+        if (e != hipSuccess) (void)hipMemUnmap((char *)base[q] + m.offset, m.bytes);
+      }
+      if (e != hipSuccess) (void)hipMemRelease(m.handle);
+    }
+    if (e != hipSuccess) {
+      set_error("mapping %zu more bytes of arena at %p + %zu failed in %s: %s", m.bytes, base[q],
+                m.offset, what, hipGetErrorString(e));
+      (void)hipGetLastError();
+      while (s->arena_maps.size() > first_new) { /* undo this step's mappings */
+        auto &u = s->arena_maps.back();
+        (void)hipMemUnmap((char *)base[u.array] + u.offset, u.bytes);
+        (void)hipMemRelease(u.handle);
+        s->arena_maps.pop_back();
+      }
+      return ERROR_DEVICE_MEMORY;
+    }
+    s->arena_maps.push_back(m);
+  }
+  return 0;
+}
+#endif
+
+/* Give the arena `pieces` pieces in all: the first allocation, or growth.  Growth keeps every
+ * record where it is -- more memory is mapped at the end of the reserved address range; without
+ * virtual memory management the arrays are re-allocated and copied -- so a solve that ran out
+ * of room is resumed, not repeated. */
 int alloc_arena(psd_problem_set *s, unsigned long long pieces) {
-  /* chunk size: about a sixteenth of what one wave will store, within [2^10, 2^16] pieces */
+  const bool first = s->d.ar_cap == 0;
   const unsigned long long n_waves = 2ull * (unsigned long long)s->n_problems;
-  int lg = psd::ARENA_CHUNK_LOG2_MIN;
-  while (lg < psd::ARENA_CHUNK_LOG2_MAX && (pieces / n_waves) >> (lg + 5)) lg++;
+  int lg = s->d.ar_chunk_log2;
+  if (first) {
+    /* chunk size: about a sixteenth of what one wave will store, within [2^10, 2^16] pieces */
+    lg = psd::ARENA_CHUNK_LOG2_MIN;
+    while (lg < psd::ARENA_CHUNK_LOG2_MAX && (pieces / n_waves) >> (lg + 5)) lg++;
+  }
   const unsigned long long chunk = 1ull << lg;
   /* whole chunks, and at least two per wave so that nobody starves at start-up */
   unsigned long long min_pieces = chunk * 2ull * n_waves;
   if (pieces < min_pieces) pieces = min_pieces;
   pieces = (pieces + chunk - 1) / chunk * chunk;
+  if (pieces <= s->d.ar_cap) return 0;
+#ifndef PSD_EMU
+  if (first && !s->arena_vmm) (void)arena_reserve(s);
+  if (s->arena_vmm) {
+    /* Mappings are whole blocks, all of the size of the first allocation (a multiple of 2^19
+     * pieces: 2 MiB of the int array): measured on ROCm 7.2 / gfx950, hipMemSetAccess refuses
+     * ranges mapped in unequal sizes or at offsets finer than 2 MiB, although the reported
+     * granularity is 4 KiB (tools/vmm_probe.cpp). */
+    if (first) s->arena_block = (pieces + 0x7ffffull) & ~0x7ffffull;
+    const unsigned long long blk = s->arena_block;
+    pieces = (pieces + blk - 1) / blk * blk;
+    if (pieces > s->arena_reserved) pieces = s->arena_reserved / blk * blk;
+    for (unsigned long long at = s->d.ar_cap; at < pieces; at += blk) {
+      int st = arena_map_more(s, at, at + blk);
+      if (st) {
+        if (at == s->d.ar_cap) return st;
+        pieces = at; /* keep what could be mapped */
+        break;
+      }
+      s->bytes += blk * 20ull;
+    }
+    s->d.ar_cap = pieces;
+    s->d.ar_chunk_log2 = lg;
+    s->arena_pieces = pieces;
+    return 0;
+  }
+#endif
+  /* plain allocations; growing = allocate, copy what has been written, free */
+  double *mx = nullptr, *prv = nullptr;
+  int *di = nullptr;
   int st;
-  if ((st = dev_alloc(s, &s->d.ar_mx, pieces))) return st;
-  if ((st = dev_alloc(s, &s->d.ar_prv, pieces))) return st;
-  if ((st = dev_alloc(s, &s->d.ar_di, pieces))) return st;
+  if ((st = dev_alloc(s, &mx, pieces)) || (st = dev_alloc(s, &prv, pieces)) ||
+      (st = dev_alloc(s, &di, pieces))) {
+    void *got[3] = {mx, prv, di};
+    const size_t sz[3] = {8, 8, 4};
+    for (int q = 0; q < 3; q++)
+      if (got[q]) {
+        forget_alloc(s, got[q]);
+        (void)hipFree(got[q]);
+        s->bytes -= pieces * sz[q];
+      }
+    return st;
+  }
+  if (!first) {
+    const size_t n = (size_t)s->d.ar_cap;
+    HIP_TRY(hipMemcpy(mx, s->d.ar_mx, n * 8, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(prv, s->d.ar_prv, n * 8, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(di, s->d.ar_di, n * 4, hipMemcpyDeviceToDevice));
+    void *old[3] = {s->d.ar_mx, s->d.ar_prv, s->d.ar_di};
+    for (void *q : old) {
+      forget_alloc(s, q);
+      (void)hipFree(q);
+    }
+    s->bytes -= s->d.ar_cap * 20ull;
+  }
+  s->d.ar_mx = mx;
+  s->d.ar_prv = prv;
+  s->d.ar_di = di;
   s->d.ar_cap = pieces;
   s->d.ar_chunk_log2 = lg;
   s->arena_pieces = pieces;
@@ -482,6 +667,7 @@ extern "C" void peakseg_hip_set_print(void (*print)(const char *)) { g_print = p
 
 extern "C" void peakseg_hip_problem_set_destroy(psd_problem_set *s) {
   if (!s) return;
+  if (s->d.ar_cap || s->arena_vmm) free_arena(s);
   for (void *q : s->allocs) (void)hipFree(q);
   for (auto &e : s->ev)
     if (e) (void)hipEventDestroy(e);
@@ -495,6 +681,14 @@ extern "C" void peakseg_hip_problem_set_destroy(psd_problem_set *s) {
 extern "C" const char *peakseg_hip_problem_set_kernel_build(psd_problem_set *s) {
   if (s->throughput && s->n_lat_mixed > 0) return "lat+thr";
   return s->throughput ? "thr" : "lat";
+}
+
+extern "C" int peakseg_hip_problem_set_solve_stats(psd_problem_set *s, int *launches,
+                                                   unsigned long long *steps_run) {
+  if (!s) return -1;
+  if (launches) *launches = s->launches;
+  if (steps_run) *steps_run = s->steps_run;
+  return 0;
 }
 
 extern "C" unsigned long long peakseg_hip_problem_set_bytes(psd_problem_set *s) {
@@ -602,6 +796,11 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
   s->ckpt_interval = K;
   long long fn_off = 0, seg_off = 0, ckpt_off = 0;
   std::vector<long long> prob_ckpt_off;
+  /* Full store: one park slot per problem (13 KB), so that a solve that runs out of arena is
+   * resumed after the arena has grown instead of repeated (PEAKSEG_HIP_NO_PARK=1: as rounds
+   * 1-2, rerun the set; sets of more than 16384 problems do without, too). */
+  const bool park = K == 0 && n_problems <= 16384 && !getenv("PEAKSEG_HIP_NO_PARK");
+  s->can_park = park;
   for (int p = 0; p < n_problems; p++) {
     int c = problem_contig[p];
     const long long n = s->contig_n[(size_t)c];
@@ -609,7 +808,7 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
     s->prob_penalty.push_back(problem_penalty[p]);
     s->prob_fn_off.push_back(fn_off);
     s->prob_seg_off.push_back(seg_off);
-    prob_ckpt_off.push_back(ckpt_off);
+    prob_ckpt_off.push_back(K > 0 ? ckpt_off : (park ? (long long)p : 0ll));
     fn_off += K > 0 ? 2ll * (K + 1) : 2ll * n;
     seg_off += n + 1;
     if (K > 0) ckpt_off += (n - 1) / K;
@@ -658,18 +857,32 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
   d.ckpt_ovf_i32 = nullptr;
   d.ckpt_ovf_cap = 0;
   d.ckpt_ovf_next = nullptr;
-  if (K > 0) {
+  d.prob_resume = nullptr;
+  s->resume_t.assign((size_t)n_problems, 0);
+  if ((st = dev_alloc(s, &s->d_order_sub, (size_t)n_problems))) {
+    peakseg_hip_problem_set_destroy(s);
+    return st;
+  }
+  if (park) {
+    if ((st = dev_alloc(s, &s->d_resume, (size_t)n_problems))) {
+      peakseg_hip_problem_set_destroy(s);
+      return st;
+    }
+    HIP_TRY(hipMemset(s->d_resume, 0, sizeof(int) * (size_t)n_problems));
+    d.prob_resume = s->d_resume;
+  }
+  if (K > 0 || park) {
     const size_t cap = (size_t)d.ckpt_cap;
-    const size_t slots = (size_t)(ckpt_off > 0 ? ckpt_off : 1);
-    if ((st = dev_alloc(s, &d.ckpt_f64, slots * (4 + 12 * cap))) ||
-        (st = dev_alloc(s, &d.ckpt_i32, slots * (2 + 2 * cap))) ||
+    const size_t slots = K > 0 ? (size_t)(ckpt_off > 0 ? ckpt_off : 1) : (size_t)n_problems;
+    if ((st = dev_alloc(s, &d.ckpt_f64, slots * (6 + 12 * cap))) ||
+        (st = dev_alloc(s, &d.ckpt_i32, slots * (8 + 2 * cap))) ||
         (st = dev_alloc(s, &d.ckpt_ovf_next, (size_t)1)) ||
         /* checkpoints of functions with more than ckpt_cap pieces (adversarial data):
          * PEAKSEG_HIP_CKPT_OVERFLOW pieces to start with (default 2^18 = 13 MB), four times as
          * many and a rerun whenever that proves too small */
         (st = alloc_ckpt_overflow(s, env_bytes("PEAKSEG_HIP_CKPT_OVERFLOW")
                                          ? env_bytes("PEAKSEG_HIP_CKPT_OVERFLOW")
-                                         : (1ull << 18)))) {
+                                         : (K > 0 ? (1ull << 18) : (1ull << 16))))) {
       peakseg_hip_problem_set_destroy(s);
       return st;
     }
@@ -807,6 +1020,18 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
     }
     s->n_lat_mixed = best_l;
   }
+  /* Launches.  The first one runs every problem.  When problems come back unfinished for
+   * want of room (arena, spill pool, checkpoint overflow pool) the host enlarges what was short
+   * and launches THOSE problems again: a problem that ran out of arena was parked by the kernel
+   * and goes on at the data point it had reached (the arena grows by a segment, its records
+   * stay in place); the others start over.  Finished problems are never computed twice. */
+  std::vector<int> todo(s->order); /* launch order: longest contig first */
+  std::fill(s->resume_t.begin(), s->resume_t.end(), 0);
+  if (s->can_park) HIP_TRY(hipMemsetAsync(s->d_resume, 0, sizeof(int) * (size_t)s->n_problems, s->stream));
+  HIP_TRY(hipMemsetAsync(s->d.ar_next_chunk, 0, sizeof(unsigned long long), s->stream));
+  s->launches = 0;
+  s->steps_run = 0;
+  float total_ms = 0.f;
   for (int attempt = 0;; attempt++) {
     if (s->ckpt_interval > 0 &&
         s->d.ar_cap < s->d.ckpt_region * 2ull * (unsigned long long)s->n_problems) {
@@ -814,15 +1039,30 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
                 s->d.ar_cap, 2 * s->n_problems, s->d.ckpt_region);
       return ERROR_DEVICE_MEMORY;
     }
-    HIP_TRY(hipMemsetAsync(s->d.ar_next_chunk, 0, sizeof(unsigned long long), s->stream));
+    const int n_todo = (int)todo.size();
+    const bool relaunch = attempt > 0;
+    psd::DeviceArgs d_run = s->d;
+    if (relaunch) {
+      /* only the unfinished problems, in their original order */
+      HIP_TRY(hipMemcpyAsync(s->d_order_sub, todo.data(), sizeof(int) * (size_t)n_todo,
+                             hipMemcpyHostToDevice, s->stream));
+      d_run.prob_order = s->d_order_sub;
+      if (s->can_park)
+        HIP_TRY(hipMemcpyAsync(s->d_resume, s->resume_t.data(), sizeof(int) * (size_t)s->n_problems,
+                               hipMemcpyHostToDevice, s->stream));
+      d_run.n_problems = n_todo;
+    }
+    if (s->ckpt_interval > 0)
+      HIP_TRY(hipMemsetAsync(s->d.ar_next_chunk, 0, sizeof(unsigned long long), s->stream));
     HIP_TRY(hipMemsetAsync(s->d.spill_next, 0, sizeof(int), s->stream));
     if (s->d.ckpt_ovf_next)
       HIP_TRY(hipMemsetAsync(s->d.ckpt_ovf_next, 0, sizeof(unsigned long long), s->stream));
-    HIP_TRY(hipMemcpyAsync(const_cast<psd::DeviceArgs *>(s->d.self), &s->d, sizeof(psd::DeviceArgs),
+    HIP_TRY(hipMemcpyAsync(const_cast<psd::DeviceArgs *>(s->d.self), &d_run, sizeof(psd::DeviceArgs),
                            hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipEventRecord(s->ev[0], s->stream));
-    const dim3 grid((unsigned)s->n_problems);
-    if (s->throughput && s->n_lat_mixed > 0) {
+    const dim3 grid((unsigned)n_todo);
+    const bool thr_now = relaunch ? (forced ? s->throughput : n_todo > s->n_cu) : s->throughput;
+    if (!relaunch && s->throughput && s->n_lat_mixed > 0) {
       /* mixed launch: both kernels index prob_order by their own blockIdx.x */
       const int L = s->n_lat_mixed;
       psd::DeviceArgs d_lat = s->d, d_thr = s->d;
@@ -834,7 +1074,7 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
        * a workgroup on each CU it would find none free before the packed part has drained,
        * and the two kernels would run one after the other.  So its workgroups report in (one
        * system-scope atomic each, on a pinned host word) and the packed part is launched when
-       * all of them have started -- or after two seconds, whatever they are waiting for. */
+       * all of them have started -- or after half a second, whatever they are waiting for. */
       __atomic_store_n(s->started, 0, __ATOMIC_RELEASE);
       d_lat.started = s->started;
       if (s->ckpt_interval > 0)
@@ -845,7 +1085,7 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
                            dim3(psd::lat::FORWARD_THREADS), 0, s->stream2, d_lat);
       HIP_TRY(hipGetLastError());
       (void)hipStreamQuery(s->stream2); /* submit now */
-      if (attempt == 0 && !s->mixed_wait_timed_out) { /* reruns and later solves after a time-out do not wait again */
+      if (!s->mixed_wait_timed_out) { /* later solves after a time-out do not wait again */
         const auto t0 = std::chrono::steady_clock::now();
         while (__atomic_load_n(s->started, __ATOMIC_ACQUIRE) < L &&
                std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(500))
@@ -865,30 +1105,44 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(s->ev2, s->stream2));
       HIP_TRY(hipStreamWaitEvent(s->stream, s->ev2, 0));
-    } else if (s->throughput) {
+    } else if (thr_now) {
       if (s->ckpt_interval > 0)
         hipLaunchKernelGGL(psd::thr::fpop_forward_ckpt_kernel, grid,
-                           dim3(psd::thr::FORWARD_THREADS), 0, s->stream, s->d);
+                           dim3(psd::thr::FORWARD_THREADS), 0, s->stream, d_run);
       else
         hipLaunchKernelGGL(psd::thr::fpop_forward_kernel, grid, dim3(psd::thr::FORWARD_THREADS),
-                           0, s->stream, s->d);
+                           0, s->stream, d_run);
     } else {
       if (s->ckpt_interval > 0)
         hipLaunchKernelGGL(psd::lat::fpop_forward_ckpt_kernel, grid,
-                           dim3(psd::lat::FORWARD_THREADS), 0, s->stream, s->d);
+                           dim3(psd::lat::FORWARD_THREADS), 0, s->stream, d_run);
       else
         hipLaunchKernelGGL(psd::lat::fpop_forward_kernel, grid, dim3(psd::lat::FORWARD_THREADS),
-                           0, s->stream, s->d);
+                           0, s->stream, d_run);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[1], s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     float f_ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&f_ms, s->ev[0], s->ev[1]));
-    if (forward_ms) *forward_ms = f_ms;
+    total_ms += f_ms;
+    s->launches++;
+    if (forward_ms) *forward_ms = total_ms;
     if (backtrack_ms) *backtrack_ms = 0.f; /* decoding happens inside the forward kernel */
-    HIP_TRY(hipMemcpy(s->results.data(), s->d.result,
-                      sizeof(psd::ProbResult) * (size_t)s->n_problems, hipMemcpyDeviceToHost));
+    {
+      /* results of the problems this launch ran (the others keep theirs) */
+      std::vector<psd::ProbResult> all((size_t)s->n_problems);
+      HIP_TRY(hipMemcpy(all.data(), s->d.result, sizeof(psd::ProbResult) * (size_t)s->n_problems,
+                        hipMemcpyDeviceToHost));
+      for (int p : todo) {
+        const psd::ProbResult &r = all[(size_t)p];
+        const int n = s->contig_n[(size_t)s->prob_contig[(size_t)p]];
+        const int reached = r.status == 0 ? n : r.step_reached;
+        if (reached > s->resume_t[(size_t)p])
+          s->steps_run += (unsigned long long)(reached - s->resume_t[(size_t)p]);
+        s->results[(size_t)p] = r;
+      }
+    }
     {
       unsigned long long chunks = 0;
       HIP_TRY(hipMemcpy(&chunks, s->d.ar_next_chunk, sizeof chunks, hipMemcpyDeviceToHost));
@@ -897,16 +1151,34 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
     }
     bool arena_full = false, spill_full = false, ckpt_full = false;
     int longest_function = 0;
-    for (auto &r : s->results) {
+    std::vector<int> again;
+    for (int p : todo) {
+      const psd::ProbResult &r = s->results[(size_t)p];
       arena_full = arena_full || r.status == psd::PST_ARENA_FULL;
       spill_full = spill_full || r.status == psd::PST_SPILL_FULL;
       ckpt_full = ckpt_full || r.status == psd::PST_CKPT_FULL;
       if (r.max_intervals > longest_function) longest_function = r.max_intervals;
+      if (r.status == psd::PST_ARENA_FULL || r.status == psd::PST_SPILL_FULL ||
+          r.status == psd::PST_CKPT_FULL) {
+        again.push_back(p);
+        /* parked: go on where it stopped; anything else starts over */
+        s->resume_t[(size_t)p] =
+            (r.status == psd::PST_ARENA_FULL && r.parked && s->can_park) ? r.step_reached : 0;
+      }
     }
-    if (!arena_full && !spill_full && !ckpt_full) break;
+    if (again.empty()) break;
+    if (getenv("PEAKSEG_HIP_TIMING")) {
+      fprintf(stderr, "peakseg_hip timing: launch %d: %d of %d problems unfinished (arena %d, spill "
+                      "pool %d, checkpoint pool %d):", s->launches, (int)again.size(), n_todo,
+              (int)arena_full, (int)spill_full, (int)ckpt_full);
+      for (size_t k = 0; k < again.size() && k < 8; k++)
+        fprintf(stderr, " p%d@%d%s", again[k], s->results[(size_t)again[k]].step_reached,
+                s->resume_t[(size_t)again[k]] ? "(parked)" : "");
+      fprintf(stderr, "\n");
+    }
     if (attempt >= 8) {
       set_error("cost-function arena (%llu pieces) / spill pool (%d slots) still too small after "
-                "%d reruns", s->arena_pieces, s->spill_slots, attempt);
+                "%d relaunches", s->arena_pieces, s->spill_slots, attempt);
       return ERROR_DEVICE_MEMORY;
     }
     if (ckpt_full) {
@@ -937,20 +1209,38 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
         set_error("cost-function arena of %llu pieces is too small", s->arena_pieces);
         return ERROR_DEVICE_MEMORY;
       }
-      /* grow and rerun the whole set: at least twice the size, and what the problems' progress
-       * says the whole set needs (pieces handed out so far / share of the data points done) */
-      unsigned long long bigger = s->arena_pieces * 2ull;
-      const unsigned long long old_ppf = s->ckpt_pieces_per_fn;
       if (s->ckpt_interval > 0) {
         /* checkpointed store: a block's records outgrew a wave's region -- twice the region,
          * or at once what the longest function of the forward pass asks for (K + 1 functions of
-         * that length always fit then) when that is more */
+         * that length always fit then) when that is more.  The regions are scratch for the
+         * decoding's recomputation: re-allocated, never kept. */
+        const unsigned long long old_ppf = s->ckpt_pieces_per_fn;
+        const unsigned long long old_pieces = s->arena_pieces;
         s->ckpt_pieces_per_fn *= 2ull;
         if (s->ckpt_pieces_per_fn < (unsigned long long)longest_function)
           s->ckpt_pieces_per_fn = (unsigned long long)longest_function;
         s->d.ckpt_region = (unsigned long long)(s->ckpt_interval + 1) * s->ckpt_pieces_per_fn;
-        bigger = s->d.ckpt_region * 2ull * (unsigned long long)s->n_problems;
+        const unsigned long long bigger = s->d.ckpt_region * 2ull * (unsigned long long)s->n_problems;
+        free_arena(s);
+        const unsigned long long fit = arena_fit(s);
+        if (bigger > fit) {
+          /* The kernel indexes region (2 p + chain) of ckpt_region pieces without looking at
+           * ar_cap: an arena clipped to what fits would be written beyond its end.  No clipping
+           * here: the regions either fit or the set does not. */
+          set_error("checkpointed store: %llu pieces per region x %d regions (%llu bytes) do not "
+                    "fit (free HBM / PEAKSEG_HIP_MAX_BYTES)", s->d.ckpt_region, 2 * s->n_problems,
+                    bigger * 20ull);
+          s->ckpt_pieces_per_fn = old_ppf;
+          s->d.ckpt_region = (unsigned long long)(s->ckpt_interval + 1) * s->ckpt_pieces_per_fn;
+          (void)alloc_arena(s, old_pieces < fit ? old_pieces : fit);
+          return ERROR_DEVICE_MEMORY;
+        }
+        int st = alloc_arena(s, bigger);
+        if (st) return st;
       } else {
+        /* Full store: the arena GROWS in place.  How much more: what the unfinished problems' progress
+         * says the rest of the set needs (pieces handed out so far x data points left / data
+         * points done, x 1.3), at least as much again as the arena has. */
         double done = 0.0, all = 0.0;
         for (int p = 0; p < s->n_problems; p++) {
           const double n = (double)s->contig_n[(size_t)s->prob_contig[(size_t)p]];
@@ -958,35 +1248,25 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
           all += n;
           done += r.status == 0 ? n : (double)r.step_reached;
         }
+        unsigned long long more = s->arena_pieces;
         if (done > 0.0) {
-          double need = (double)s->arena_pieces * (all / done) * 1.3;
-          if (need > (double)bigger) bigger = (unsigned long long)need;
+          const double need = (double)s->arena_pieces * ((all - done) / done) * 1.3;
+          if (need > (double)more) more = (unsigned long long)need;
         }
+        unsigned long long fit = arena_fit(s);
+        if (!s->arena_vmm) fit /= 2ull; /* growing by copy holds the old and the new arrays at once */
+        if (more > fit) more = fit;
+        const unsigned long long chunk = 1ull << s->d.ar_chunk_log2;
+        if (more < chunk * 4ull * (unsigned long long)again.size()) {
+          set_error("cost-function arena cannot grow beyond %llu pieces (free HBM / "
+                    "PEAKSEG_HIP_MAX_BYTES)", s->arena_pieces);
+          return ERROR_DEVICE_MEMORY;
+        }
+        int st = alloc_arena(s, s->arena_pieces + more);
+        if (st) return st;
       }
-      unsigned long long old_pieces = s->arena_pieces;
-      free_arena(s);
-      unsigned long long fit = arena_fit(s);
-      if (s->ckpt_interval > 0 && bigger > fit) {
-        /* The kernel indexes region (2 p + chain) of ckpt_region pieces without looking at
-         * ar_cap: an arena clipped to what fits would be written beyond its end.  No clipping
-         * here: the regions either fit or the set does not. */
-        set_error("checkpointed store: %llu pieces per region x %d regions (%llu bytes) do not "
-                  "fit (free HBM / PEAKSEG_HIP_MAX_BYTES)", s->d.ckpt_region, 2 * s->n_problems,
-                  bigger * 20ull);
-        s->ckpt_pieces_per_fn = old_ppf;
-        s->d.ckpt_region = (unsigned long long)(s->ckpt_interval + 1) * s->ckpt_pieces_per_fn;
-        (void)alloc_arena(s, old_pieces < fit ? old_pieces : fit);
-        return ERROR_DEVICE_MEMORY;
-      }
-      if (bigger > fit) bigger = fit;
-      if (bigger <= old_pieces) {
-        set_error("cost-function arena cannot grow beyond %llu pieces (free HBM / "
-                  "PEAKSEG_HIP_MAX_BYTES)", old_pieces);
-        return ERROR_DEVICE_MEMORY;
-      }
-      int st = alloc_arena(s, bigger);
-      if (st) return st;
     }
+    todo.swap(again);
   }
   s->solved = true;
   int first = 0;

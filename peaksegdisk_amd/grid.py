@@ -84,6 +84,15 @@ class ProblemSet:
         """bytes of the arena the last solve() handed out"""
         return int(self._lib.peakseg_hip_problem_set_arena_bytes_used(self._h))
 
+    @property
+    def solve_stats(self):
+        """(kernel launches, data points worked through) of the last solve(): one launch and the
+        sum of the problems' lengths unless a store had to grow."""
+        n = ctypes.c_int()
+        steps = ctypes.c_ulonglong()
+        self._lib.peakseg_hip_problem_set_solve_stats(self._h, ctypes.byref(n), ctypes.byref(steps))
+        return n.value, steps.value
+
     def set_penalty(self, p, penalty):
         """Change one problem's penalty in place; the next solve() reuses contig and arena."""
         if self._lib.peakseg_hip_problem_set_set_penalty(self._h, p, float(penalty)) != 0:

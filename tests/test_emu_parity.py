@@ -234,3 +234,8 @@ def test_emu_write_failures_dp_branch(psd, tmp_path, monkeypatch):
 
 def test_emu_batch_with_duplicate_problems(psd, oracle_det, tmp_path):
     gp3.test_batch_with_duplicate_problems(psd, oracle_det, tmp_path, n_bins=400)
+
+
+def test_emu_arena_regrowth_resumes(psd, oracle_det, tmp_path, monkeypatch):
+    gp3.test_arena_regrowth_resumes_instead_of_repeating(psd, oracle_det, tmp_path, monkeypatch,
+                                                         n_bins=1500)

@@ -673,6 +673,9 @@ def test_checkpointed_store_region_regrowth_and_limits(psd, tmp_path, monkeypatc
     # smaller than the regions the kernel indexes: the same adversarial data, a
     # cap just above what the set holds after its first, far too small, allocation.
     monkeypatch.setenv("PEAKSEG_HIP_PIECES_PER_FUNCTION", "1")
+    # (blocks of 2048 data points: the regions the decoding needs, 2049 functions of some 250
+    # pieces per chain, are larger than the smallest arena the library maps)
+    monkeypatch.setenv("PEAKSEG_HIP_CHECKPOINT", "2048" if adv_bins > 2500 else "256")
     probe = ProblemSet([(c2, w2)], [(0, 100.0)])
     held = probe.hbm_bytes
     probe.close()

@@ -431,3 +431,57 @@ def test_batch_with_duplicate_problems(psd, oracle_det, tmp_path, n_bins=2000):
     assert open(bg + "_penalty=3000_loss.tsv", "rb").read() == \
         open(obg + "_penalty=3000_loss.tsv", "rb").read()
     assert len(open(bg + "_penalty=3000_timing.tsv").read().split("\t")) == 3
+
+
+@GPU
+def test_arena_regrowth_resumes_instead_of_repeating(psd, oracle_det, tmp_path, monkeypatch,
+                                                     n_bins=20000):
+    """An arena estimate that is far too small (one piece per stored function): the kernel parks
+    the problems that run out of room, the host adds a segment to the arena and relaunches the
+    parked problems from the data point they had reached.  Nothing is computed twice -- the
+    launches together work through exactly the problems' data points -- and the store, now
+    spread over several segments, still equals the oracle's database byte for byte.  With
+    PEAKSEG_HIP_NO_PARK=1 (rounds 1-2: rerun from the start) the result is the same and the
+    work is not."""
+    from peaksegdisk_amd import ProblemSet, synthetic
+    cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=21)
+    w = (ce - cs).astype(np.int32)
+    pens = ["0.3", "7", "60", "500", "4000", "30000", "200000", "1000000"]
+    problems = [(0, float(p)) for p in pens]
+    monkeypatch.setenv("PEAKSEG_HIP_NO_CHECKPOINT", "1")
+    monkeypatch.setenv("PEAKSEG_HIP_PIECES_PER_FUNCTION", "1")
+    pset = ProblemSet([(cnt, w)], problems)
+    pset.solve()
+    launches, steps = pset.solve_stats
+    assert launches >= 2, "the arena was never exhausted"
+    assert steps == n_bins * len(pens), (launches, steps)
+    bg = str(tmp_path / "coverage.bedGraph")
+    synthetic.write_bedgraph(bg, cs, ce, cnt)
+    want = []
+    for i, pen in enumerate(pens):
+        r = pset.result(i)
+        assert r.status == 0
+        want.append((r.n_segments, r.max_intervals, r.total_intervals, r.best_cost)
+                    + pset.segments(i))
+        if i in (1, 4, 7):
+            db_o = str(tmp_path / ("o%d.db" % i))
+            assert oracle_det.solve(bg, pen, db_o) == 0
+            db_g = str(tmp_path / ("g%d.db" % i))
+            pset.export_db(i, ce, db_g)
+            assert open(db_g, "rb").read() == open(db_o, "rb").read(), pen
+    # a second solve of the same set reuses the grown arena: one launch
+    pset.solve()
+    assert pset.solve_stats == (1, n_bins * len(pens))
+    pset.close()
+    monkeypatch.setenv("PEAKSEG_HIP_NO_PARK", "1")
+    rerun = ProblemSet([(cnt, w)], problems)
+    rerun.solve()
+    launches2, steps2 = rerun.solve_stats
+    assert launches2 >= 2 and steps2 > n_bins * len(pens)
+    for i in range(len(pens)):
+        r = rerun.result(i)
+        got = (r.n_segments, r.max_intervals, r.total_intervals, r.best_cost) + rerun.segments(i)
+        assert got[:4] == want[i][:4]
+        assert np.array_equal(got[4], want[i][4])
+        assert np.array_equal(got[5].view(np.uint64), want[i][5].view(np.uint64))
+    rerun.close()
