@@ -342,7 +342,7 @@ def main():
         # rocprofv3 --pmc by tools/collect_profiles.sh); only valid for that workload
         traffic = None
         if args.mode == "weak":
-            for rnd in ("r02", "r01"):
+            for rnd in ("r03", "r02", "r01"):
                 try:
                     with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as f:
                         pmc = json.load(f)

@@ -974,6 +974,10 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
   return 0;
 }
 
+/* what the mixed-launch planner assumes a problem advances at, refreshed by every solve that
+ * ran on one build alone with every problem resident from the start (a clean measurement) */
+static std::atomic<double> g_lat_rate{90e3}, g_thr_rate{27e3};
+
 extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_ms,
                                              float *backtrack_ms) {
   HIP_TRY(hipSetDevice(s->device));
@@ -994,7 +998,10 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
    * predicted ends.  (Equal contigs: L = 0.) */
   s->n_lat_mixed = 0;
   if (s->throughput && !forced) {
-    const double lat_rate = 90e3, thr_rate = 27e3, thr_per_cu = 4.0;
+    /* data points per second of one problem on either build: measured by this process's own
+     * earlier solves when there were any (g_lat_rate / g_thr_rate below), else the figures of
+     * an MI355X at 2.4 GHz */
+    const double lat_rate = g_lat_rate.load(), thr_rate = g_thr_rate.load(), thr_per_cu = 4.0;
     std::vector<double> len((size_t)s->n_problems);
     double rest = 0.0;
     for (int k = 0; k < s->n_problems; k++) {
@@ -1267,6 +1274,21 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
       }
     }
     todo.swap(again);
+  }
+  if (s->launches == 1 && s->n_lat_mixed == 0 && s->ckpt_interval == 0 && total_ms > 50.f) {
+    /* a clean single launch: the longest problem's data points / kernel time is the rate of
+     * that build (the throughput build only while every workgroup was resident at once) */
+    int longest = 0;
+    bool spilled = false;
+    for (int p = 0; p < s->n_problems; p++) {
+      longest = std::max(longest, s->contig_n[(size_t)s->prob_contig[(size_t)p]]);
+      spilled = spilled || s->results[(size_t)p].spill_steps > 0;
+    }
+    const double rate = (double)longest / ((double)total_ms / 1e3);
+    if (!spilled && rate > 1e3 && rate < 1e7) {
+      if (!s->throughput && s->n_problems <= s->n_cu) g_lat_rate.store(rate);
+      if (s->throughput && s->n_problems <= 4 * s->n_cu) g_thr_rate.store(rate);
+    }
   }
   s->solved = true;
   int first = 0;
