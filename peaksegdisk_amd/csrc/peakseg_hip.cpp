@@ -1275,7 +1275,8 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
     }
     todo.swap(again);
   }
-  if (s->launches == 1 && s->n_lat_mixed == 0 && s->ckpt_interval == 0 && total_ms > 50.f) {
+#ifndef PSD_EMU /* (the emulator's timings say nothing about the hardware) */
+  if (s->launches == 1 && s->n_lat_mixed == 0 && s->ckpt_interval == 0 && total_ms > 500.f) {
     /* a clean single launch: the longest problem's data points / kernel time is the rate of
      * that build (the throughput build only while every workgroup was resident at once) */
     int longest = 0;
@@ -1286,10 +1287,14 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
     }
     const double rate = (double)longest / ((double)total_ms / 1e3);
     if (!spilled && rate > 1e3 && rate < 1e7) {
+      /* latency build: a CU per problem; throughput build: only a chip that was full (four
+       * workgroups on nearly every CU) shows the packed rate the planner reasons with */
       if (!s->throughput && s->n_problems <= s->n_cu) g_lat_rate.store(rate);
-      if (s->throughput && s->n_problems <= 4 * s->n_cu) g_thr_rate.store(rate);
+      if (s->throughput && s->n_problems <= 4 * s->n_cu && s->n_problems >= 7 * s->n_cu / 2)
+        g_thr_rate.store(rate);
     }
   }
+#endif
   s->solved = true;
   int first = 0;
   for (int p = 0; p < s->n_problems; p++) {
