@@ -158,53 +158,3 @@ PSD_HD static inline void PSD_FN(psd_exp2_log)(double x0, double x1, double z, d
   *y1 = r1;
   *lz = rz;
 }
-
-/* exp for the Newton iteration in log-mean space only (get_smaller_root): table-free.
- * x = k ln2 + r, |r| <= ln2/2; exp(r) = 1 + r + r^2 P(r), P = the Taylor polynomial 1/2 ..
- * r^11/13! (truncation < 5e-18); exp(x) = 2^k (1 + t_hi + t_lo) with t_hi = r + q and
- * t_lo = (r - t_hi) + q exactly (Fast2Sum).  0.90 ulp at worst where psd_exp has 0.51
- * (tests/test_detmath.py), and 72 cycles per call faster on gfx950 (156 -> 84, one wave alone:
- * the table look-up of psd_exp sits in the middle of its dependent chain and a lone wave waits
- * ~110 cycles for it; tools/math_probe.cpp).
- *
- * Only the iterates of a Newton solve are computed with it.  The iteration is self-correcting:
- * it ends when |cost| <= 1e-12 whatever the last bits of the exp were, so the root it returns
- * moves by less than the tolerance already allows -- unlike the costs that the list operations
- * compare against 1e-12, which keep psd_exp: with this exp used for them too, the
- * deterministic arithmetic left the glibc arithmetic's segmentations at 2 of 4 penalties on
- * 3e5 bins (profiles/r03/probe_results.log). */
-PSD_HD static inline double PSD_FN(psd_expn_fast)(double x) {
-  const double shift = PSD_K(0x1.8p52);
-  double z = psd_fma(x, PSD_K(PSD_INV_LN2), shift); /* low mantissa bits: rint(x / ln2) */
-  const long long k = (long long)psd_d2u(z) - (long long)0x4338000000000000LL;
-  double kd = z - shift;
-  double r = psd_fma(kd, PSD_K(-PSD_LN2_HI), x); /* exact: LN2_HI has 32 bits */
-  r = psd_fma(kd, PSD_K(-PSD_LN2_LO), r);
-  double p = PSD_K(0x1.6124613a86d09p-33);        /* 1/13! */
-  p = psd_fma(p, r, PSD_K(0x1.1eed8eff8d898p-29)); /* 1/12! */
-  p = psd_fma(p, r, PSD_K(0x1.ae64567f544e4p-26)); /* 1/11! */
-  p = psd_fma(p, r, PSD_K(0x1.27e4fb7789f5cp-22)); /* 1/10! */
-  p = psd_fma(p, r, PSD_K(0x1.71de3a556c734p-19)); /* 1/9! */
-  p = psd_fma(p, r, PSD_K(0x1.a01a01a01a01ap-16)); /* 1/8! */
-  p = psd_fma(p, r, PSD_K(0x1.a01a01a01a01ap-13)); /* 1/7! */
-  p = psd_fma(p, r, PSD_K(0x1.6c16c16c16c17p-10)); /* 1/6! */
-  p = psd_fma(p, r, PSD_K(0x1.1111111111111p-7));  /* 1/5! */
-  p = psd_fma(p, r, PSD_K(0x1.5555555555555p-5));  /* 1/4! */
-  p = psd_fma(p, r, PSD_K(0x1.5555555555555p-3));  /* 1/3! */
-  p = psd_fma(p, r, 0.5);
-  double q = (r * r) * p;
-  double t_hi = r + q;
-  double t_lo = (r - t_hi) + q;
-  double scale = psd_u2d((uint64_t)(k + 1023) << 52); /* 2^k, k in [-1022, 1022] */
-  return psd_fma(scale, t_lo, psd_fma(scale, t_hi, scale));
-}
-/* the same with the rare arguments (|x| > 708, NaN) handed to psd_exp's slow path */
-PSD_HD static inline double PSD_FN(psd_expn)(double x) {
-  double y = PSD_FN(psd_expn_fast)(x);
-  const int rare = !(__builtin_fabs(x) <= 708.0);
-  if (PSD_ANY_LANE(rare)) {
-    const double ys = psd_exp_slow(x);
-    y = rare ? ys : y;
-  }
-  return y;
-}

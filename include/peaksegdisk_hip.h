@@ -39,7 +39,7 @@ extern "C" {
  *                               per GPU sets it from its rank
  * PEAKSEG_HIP_MAX_BYTES         cap on the HBM one problem set may hold (suffix K/M/G/T); several
  *                               processes can then share one GPU (R's future workers)
- * PEAKSEG_HIP_PIECES_PER_FUNCTION  arena estimate, pieces per stored cost function (default 16;
+ * PEAKSEG_HIP_PIECES_PER_FUNCTION  arena estimate, pieces per stored cost function (default 10;
  *                               the arena is doubled and the set rerun when it proves too small)
  * PEAKSEG_HIP_SPILL_CAP / _SPILL_SLOTS  capacity (pieces per list, at most 32767) and initial
  *                               number of slots of the HBM spill pool for functions that outgrow LDS

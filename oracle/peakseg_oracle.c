@@ -17,15 +17,11 @@
 
 #ifdef ORACLE_LIBM
 #define O_EXP(x) exp(x)
-#define O_EXPN(x) exp(x)
 #define O_LOG(x) log(x)
 #define O_MATH_KIND "libm"
 #else
 #include "peakseg_detmath.h"
 #define O_EXP(x) psd_exp(x)
-/* the iterates of the log-mean-space Newton solve: the table-free exp the kernels use there
- * (include/peakseg_detmath_core.h, psd_expn); the reference calls exp() for both */
-#define O_EXPN(x) psd_expn(x)
 #define O_LOG(x) psd_log(x)
 #define O_MATH_KIND "detmath"
 #endif
@@ -115,32 +111,6 @@ static double piece_getCost(const piece_t *q, double log_mean) {
     log_term = q->Log * log_mean;
   }
   return linear_term + log_term + q->Constant;
-}
-
-/* getCost / getDeriv at an iterate of get_smaller_root's Newton loop (same code; the exp is
- * O_EXPN, see above) */
-static double piece_getCost_newton(const piece_t *q, double log_mean) {
-  double linear_term, log_term;
-  if (log_mean == -INFINITY) {
-    linear_term = 0.0;
-  } else {
-    linear_term = q->Linear * O_EXPN(log_mean);
-  }
-  if (q->Log == 0) {
-    log_term = 0.0;
-  } else {
-    log_term = q->Log * log_mean;
-  }
-  return linear_term + log_term + q->Constant;
-}
-static double piece_getDeriv_newton(const piece_t *q, double log_mean) {
-  double linear_term;
-  if (log_mean == -INFINITY) {
-    linear_term = 0.0;
-  } else {
-    linear_term = q->Linear * O_EXPN(log_mean);
-  }
-  return linear_term + q->Log;
 }
 
 /* ref: fpl:224-234 */
@@ -257,7 +227,7 @@ static double piece_get_smaller_root(const piece_t *q, double equals) {
   int step = 0;
   double offset;
   do {
-    candidate_cost = piece_getCost_newton(q, candidate_root) - equals;
+    candidate_cost = piece_getCost(q, candidate_root) - equals;
     if (0 < candidate_cost && candidate_cost < closest_positive_cost) {
       closest_positive_cost = candidate_cost;
       closest_positive_log_mean = candidate_root;
@@ -275,7 +245,7 @@ static double piece_get_smaller_root(const piece_t *q, double equals) {
         return candidate_root;
       }
     }
-    deriv = piece_getDeriv_newton(q, candidate_root);
+    deriv = piece_getDeriv(q, candidate_root);
     offset = candidate_cost / deriv;
     possibly_outside = candidate_root - offset;
     candidate_root = possibly_outside;

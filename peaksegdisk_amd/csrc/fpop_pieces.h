@@ -58,17 +58,6 @@ PSD_D double d_exp(double x) { return psd_exp(x); }
 PSD_D double d_log(double x) { return psd_log(x); }
 #endif
 
-/* exp at an iterate of the log-mean-space Newton solve (psd_expn: table-free, see
- * include/peakseg_detmath_core.h).  Measured on the 100 k x 64 grid, same box
- * (profiles/r03/ab_newton_exp.log): table exp 1177 ms; this one with its thirteen polynomial
- * constants as literals 1232 ms (each use costs two scalar moves in a kernel short of scalar
- * registers); with the constants in vector registers 1149 ms. */
-#if defined(__HIP_DEVICE_COMPILE__) && (defined(PSD_MATH_VK) || defined(PSD_EXPN_VK)) && \
-    !defined(PSD_EXPN_LITERALS)
-PSD_D double d_expn(double x) { return psd_expn_vk(x); }
-#else
-PSD_D double d_expn(double x) { return psd_expn(x); }
-#endif
 #if defined(PSD_MATH_VK) && defined(__HIP_DEVICE_COMPILE__)
 PSD_D void d_exp2(double x0, double x1, double &y0, double &y1) { psd_exp2_vk(x0, x1, &y0, &y1); }
 PSD_D void d_log2(double x0, double x1, double &y0, double &y1) { psd_log2_vk(x0, x1, &y0, &y1); }
@@ -232,7 +221,7 @@ PSD_COLD_DEV double smaller_root_full(Coef c, double optimal_log_mean, double op
   }
   int step = 0;
   do {
-    double linear_term = (candidate_root == -PSD_INF) ? 0.0 : c.Linear * d_expn(candidate_root);
+    double linear_term = (candidate_root == -PSD_INF) ? 0.0 : c.Linear * d_exp(candidate_root);
     double log_term = (c.Log == 0) ? 0.0 : c.Log * candidate_root;
     candidate_cost = (linear_term + log_term + c.Constant) - equals;
     if (0 < candidate_cost && candidate_cost < closest_positive_cost) {
@@ -275,11 +264,7 @@ PSD_D double get_smaller_root(const Coef &c, const PieceOpt &o, double min_log_m
   do {
     /* getCost and getDeriv (fpl:206-234) evaluate the same Linear*exp(x): once here */
     const bool at_zero_mean = candidate_root == -PSD_INF;
-#ifdef PSD_NEWTON_TABLE_EXP /* A/B: the table exp for the iterates (then the oracle must too) */
     double e = d_exp(at_zero_mean ? 0.0 : candidate_root);
-#else
-    double e = d_expn(at_zero_mean ? 0.0 : candidate_root);
-#endif
     double linear_term = at_zero_mean ? 0.0 : c.Linear * e;
     double log_term = (c.Log == 0) ? 0.0 : c.Log * candidate_root;
     candidate_cost = (linear_term + log_term + c.Constant) - equals;

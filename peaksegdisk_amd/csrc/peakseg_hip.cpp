@@ -774,7 +774,11 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
    * records of one block of K at a time; the decoding recomputes the blocks it walks through.
    * Chosen when the full store would not fit (free HBM / PEAKSEG_HIP_MAX_BYTES), or forced
    * with PEAKSEG_HIP_CHECKPOINT=K. */
-  double per_fn = 16.0;
+  /* pieces per stored function the arena is first sized for.  Typical coverage data needs 2-14
+   * (the 1e6 x 64 grid: 5.2 on average); an estimate that proves too small costs one more
+   * launch, not a repeated solve (the arena grows in place, parked problems go on), so the
+   * default no longer has to be generous: 10 instead of rounds 1-2's 16. */
+  double per_fn = 10.0;
   if (const char *e = getenv("PEAKSEG_HIP_PIECES_PER_FUNCTION")) {
     double v = atof(e);
     if (v >= 1.0) per_fn = v;
