@@ -356,10 +356,8 @@ def main():
         fwd_s = float(np.mean(fwd)) / 1e3
         clock_hz = None
         if on_gpu:
-            try:
-                clock_hz = torch.cuda.get_device_properties(device).clock_rate * 1e3
-            except Exception:
-                clock_hz = None
+            khz = _native.lib.peakseg_hip_device_clock_khz(device)
+            clock_hz = khz * 1e3 if khz > 0 else None
         # latency build: 4 waves per problem (two chains + helpers), throughput build: 2
         n_prob_rank0 = len(problems) if args.mode == "weak" else stats.get("problems", 0)
         wave_slots_used = n_prob_rank0 * (4 if extra.get("kernel_build") == "lat" else 2)

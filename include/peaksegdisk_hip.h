@@ -142,6 +142,8 @@ typedef struct {
 } psd_result;
 
 int peakseg_hip_device_count(void);
+/* shader clock of a device in kHz, 0 when unknown */
+int peakseg_hip_device_clock_khz(int device);
 const char *peakseg_hip_last_error(void);
 
 /* Upload contigs (count = 4th bedGraph column, weight = chromEnd-chromStart) and the

@@ -121,6 +121,8 @@ def declare(lib):
     lib.peakseg_hip_problem_set_solve_stats.argtypes = [
         c.c_void_p, c.POINTER(c.c_int), c.POINTER(c.c_ulonglong)]
     lib.peakseg_hip_problem_set_solve_stats.restype = c.c_int
+    lib.peakseg_hip_device_clock_khz.argtypes = [c.c_int]
+    lib.peakseg_hip_device_clock_khz.restype = c.c_int
     return lib
 
 
@@ -136,7 +138,7 @@ EXPORTED_SYMBOLS = [
     "PeakSegFPOP_sequential_search_batch",
     "peakseg_hip_problem_set_set_penalty", "peakseg_hip_problem_set_arena_bytes_used",
     "peakseg_hip_paste_double", "peakseg_hip_problem_set_checkpoint_interval",
-    "peakseg_hip_problem_set_solve_stats",
+    "peakseg_hip_problem_set_solve_stats", "peakseg_hip_device_clock_khz",
 ]
 
 if not os.path.exists(LIB_PATH):

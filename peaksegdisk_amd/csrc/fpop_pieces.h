@@ -195,12 +195,26 @@ PSD_D double get_larger_root(const Coef &c, const PieceOpt &o, double max_log_me
   double candidate_root = optimal_mean + 1;
   double candidate_cost;
   int step = 0;
+#ifndef PSD_NEWTON_EXIT_IN_LOOP
+  /* One way out of the loop: the reference leaves at trip NEWTON_STEPS from the middle of the
+   * body (fpl:109-120), whatever the cost there; here the loop simply ends at that trip and the
+   * complete function -- which redoes the solve with the bracket bookkeeping -- is called
+   * behind it.  Same results; a loop with a single exit and no return inside. */
+  do {
+    candidate_cost = poisson_loss(c, candidate_root) - equals;
+    ++step;
+    double deriv = c.Linear + c.Log / candidate_root; /* PoissonDeriv fpl:63-65 */
+    candidate_root = candidate_root - candidate_cost / deriv;
+  } while (NEWTON_EPSILON < absd(candidate_cost) && step < NEWTON_STEPS);
+  if (NEWTON_STEPS <= step) return larger_root_full(c, optimal_mean, optimal_cost, equals);
+#else
   do {
     candidate_cost = poisson_loss(c, candidate_root) - equals;
     if (NEWTON_STEPS <= ++step) return larger_root_full(c, optimal_mean, optimal_cost, equals);
     double deriv = c.Linear + c.Log / candidate_root; /* PoissonDeriv fpl:63-65 */
     candidate_root = candidate_root - candidate_cost / deriv;
   } while (NEWTON_EPSILON < absd(candidate_cost));
+#endif
   if (steps_out) *steps_out = step;
   return d_log(candidate_root);
 }
@@ -268,12 +282,21 @@ PSD_D double get_smaller_root(const Coef &c, const PieceOpt &o, double min_log_m
     double linear_term = at_zero_mean ? 0.0 : c.Linear * e;
     double log_term = (c.Log == 0) ? 0.0 : c.Log * candidate_root;
     candidate_cost = (linear_term + log_term + c.Constant) - equals;
+#ifdef PSD_NEWTON_EXIT_IN_LOOP
     if (NEWTON_STEPS <= ++step)
       return smaller_root_full(c, optimal_log_mean, optimal_cost, equals);
+#else
+    ++step; /* the step cap ends the loop; see get_larger_root */
+#endif
     double deriv = linear_term + c.Log;
     double offset = candidate_cost / deriv;
     candidate_root = candidate_root - offset;
+#ifdef PSD_NEWTON_EXIT_IN_LOOP
   } while (NEWTON_EPSILON < absd(candidate_cost));
+#else
+  } while (NEWTON_EPSILON < absd(candidate_cost) && step < NEWTON_STEPS);
+  if (NEWTON_STEPS <= step) return smaller_root_full(c, optimal_log_mean, optimal_cost, equals);
+#endif
   if (steps_out) *steps_out = step;
   return candidate_root;
 }

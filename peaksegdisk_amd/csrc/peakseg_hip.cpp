@@ -663,6 +663,14 @@ extern "C" int peakseg_hip_device_count(void) {
 
 extern "C" const char *peakseg_hip_last_error(void) { return g_last_error.c_str(); }
 
+/* shader clock of a device in kHz (0 when unknown): bench.py turns kernel time into cycles per
+ * data point with it */
+extern "C" int peakseg_hip_device_clock_khz(int device) {
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, device) != hipSuccess) return 0;
+  return khz;
+}
+
 extern "C" void peakseg_hip_set_print(void (*print)(const char *)) { g_print = print; }
 
 extern "C" void peakseg_hip_problem_set_destroy(psd_problem_set *s) {

@@ -98,7 +98,7 @@ struct emu_event {
 typedef emu_event *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 
-enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount };
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount, hipDeviceAttributeClockRate };
 hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t a, int device);
 hipError_t hipGetDeviceCount(int *n);
 hipError_t hipSetDevice(int d);
