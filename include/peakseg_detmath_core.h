@@ -158,3 +158,21 @@ PSD_HD static inline void PSD_FN(psd_exp2_log)(double x0, double x1, double z, d
   *y1 = r1;
   *lz = rz;
 }
+
+/* The hot path of psd_exp / psd_log WITHOUT the branch to the rare-argument path: the value is
+ * psd_exp(x) / psd_log(x) whenever *rare stays 0 and unspecified (but harmless) otherwise.  For
+ * the Newton loops, which evaluate one of them per trip: the loop only records that a rare
+ * argument was met; the solve is then redone with the complete functions (never on real data). */
+PSD_HD static inline double PSD_FN(psd_exp_nb)(double x, int *rare) {
+  long long kq;
+  double hi;
+  double t = PSD_FN(psd_exp_core)(x, &kq, &hi);
+  double scale = psd_u2d(psd_d2u(hi) + ((uint64_t)(kq >> 7) << 52));
+  *rare |= !(__builtin_fabs(x) <= 708.0);
+  return psd_fma(scale, t, scale);
+}
+PSD_HD static inline double PSD_FN(psd_log_nb)(double x, int *rare) {
+  const uint64_t hx = psd_d2u(x);
+  *rare |= !((uint32_t)(hx >> 32) - 0x00100000u < 0x7fe00000u);
+  return PSD_FN(psd_log_core)(hx, 0);
+}

@@ -59,6 +59,13 @@ PSD_D double d_log(double x) { return psd_log(x); }
 #endif
 
 #if defined(PSD_MATH_VK) && defined(__HIP_DEVICE_COMPILE__)
+PSD_D double d_exp_nb(double x, int &rare) { return psd_exp_nb_vk(x, &rare); }
+PSD_D double d_log_nb(double x, int &rare) { return psd_log_nb_vk(x, &rare); }
+#else
+PSD_D double d_exp_nb(double x, int &rare) { return psd_exp_nb(x, &rare); }
+PSD_D double d_log_nb(double x, int &rare) { return psd_log_nb(x, &rare); }
+#endif
+#if defined(PSD_MATH_VK) && defined(__HIP_DEVICE_COMPILE__)
 PSD_D void d_exp2(double x0, double x1, double &y0, double &y1) { psd_exp2_vk(x0, x1, &y0, &y1); }
 PSD_D void d_log2(double x0, double x1, double &y0, double &y1) { psd_log2_vk(x0, x1, &y0, &y1); }
 PSD_D void d_exp2_log(double x0, double x1, double z, double &y0, double &y1, double &lz) {
@@ -200,6 +207,22 @@ PSD_D double get_larger_root(const Coef &c, const PieceOpt &o, double max_log_me
    * body (fpl:109-120), whatever the cost there; here the loop simply ends at that trip and the
    * complete function -- which redoes the solve with the bracket bookkeeping -- is called
    * behind it.  Same results; a loop with a single exit and no return inside. */
+#ifndef PSD_NEWTON_RARE_BRANCH
+  /* ... and no branch to log's rare-argument path inside it: the loop records that it met such
+   * an argument (a mean <= 0, a subnormal, Inf, NaN: an iteration gone astray) and the solve is
+   * then redone by the complete function, which handles them as the reference's libm does. */
+  int rare = 0;
+  do {
+    const double loss_without_log_term = c.Linear * candidate_root + c.Constant; /* fpl:52-61 */
+    const double product = d_log_nb(candidate_root, rare) * c.Log;
+    candidate_cost = ((c.Log == 0) ? loss_without_log_term : loss_without_log_term + product) - equals;
+    ++step;
+    double deriv = c.Linear + c.Log / candidate_root; /* PoissonDeriv fpl:63-65 */
+    candidate_root = candidate_root - candidate_cost / deriv;
+  } while (NEWTON_EPSILON < absd(candidate_cost) && step < NEWTON_STEPS);
+  if (NEWTON_STEPS <= step || rare != 0)
+    return larger_root_full(c, optimal_mean, optimal_cost, equals);
+#else
   do {
     candidate_cost = poisson_loss(c, candidate_root) - equals;
     ++step;
@@ -207,6 +230,7 @@ PSD_D double get_larger_root(const Coef &c, const PieceOpt &o, double max_log_me
     candidate_root = candidate_root - candidate_cost / deriv;
   } while (NEWTON_EPSILON < absd(candidate_cost) && step < NEWTON_STEPS);
   if (NEWTON_STEPS <= step) return larger_root_full(c, optimal_mean, optimal_cost, equals);
+#endif
 #else
   do {
     candidate_cost = poisson_loss(c, candidate_root) - equals;
@@ -275,10 +299,17 @@ PSD_D double get_smaller_root(const Coef &c, const PieceOpt &o, double min_log_m
   double candidate_root = optimal_log_mean - 1;
   double candidate_cost;
   int step = 0;
+#ifndef PSD_NEWTON_RARE_BRANCH
+  int rare = 0; /* an exp argument beyond +-708 or NaN was met: redo with the complete function */
+#endif
   do {
     /* getCost and getDeriv (fpl:206-234) evaluate the same Linear*exp(x): once here */
     const bool at_zero_mean = candidate_root == -PSD_INF;
+#ifndef PSD_NEWTON_RARE_BRANCH
+    double e = d_exp_nb(at_zero_mean ? 0.0 : candidate_root, rare);
+#else
     double e = d_exp(at_zero_mean ? 0.0 : candidate_root);
+#endif
     double linear_term = at_zero_mean ? 0.0 : c.Linear * e;
     double log_term = (c.Log == 0) ? 0.0 : c.Log * candidate_root;
     candidate_cost = (linear_term + log_term + c.Constant) - equals;
@@ -295,7 +326,12 @@ PSD_D double get_smaller_root(const Coef &c, const PieceOpt &o, double min_log_m
   } while (NEWTON_EPSILON < absd(candidate_cost));
 #else
   } while (NEWTON_EPSILON < absd(candidate_cost) && step < NEWTON_STEPS);
-  if (NEWTON_STEPS <= step) return smaller_root_full(c, optimal_log_mean, optimal_cost, equals);
+#ifndef PSD_NEWTON_RARE_BRANCH
+  if (NEWTON_STEPS <= step || rare != 0)
+#else
+  if (NEWTON_STEPS <= step)
+#endif
+    return smaller_root_full(c, optimal_log_mean, optimal_cost, equals);
 #endif
   if (steps_out) *steps_out = step;
   return candidate_root;
