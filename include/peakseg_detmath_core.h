@@ -173,6 +173,28 @@ PSD_HD static inline double PSD_FN(psd_exp_nb)(double x, int *rare) {
 }
 PSD_HD static inline double PSD_FN(psd_log_nb)(double x, int *rare) {
   const uint64_t hx = psd_d2u(x);
-  *rare |= !((uint32_t)(hx >> 32) - 0x00100000u < 0x7fe00000u);
-  return PSD_FN(psd_log_core)(hx, 0);
+  /* A negative argument is not rare: the reference takes the log of negative quotients as a
+   * matter of course (funPieceListLog.cpp:563,996: the crossing of degenerate pieces) and
+   * lets the NaN fail every comparison.  NaN by a select; the record is for 0, subnormals, Inf
+   * and NaN only. */
+  const int negative = x < 0.0;
+  *rare |= !((uint32_t)(hx >> 32) - 0x00100000u < 0x7fe00000u) && !negative;
+  const double y = PSD_FN(psd_log_core)(hx, 0);
+  return negative ? psd_u2d(0x7ff8000000000000ULL) : y;
+}
+
+/* psd_log_nb for a site whose argument is a quotient that may be anything -- a division by the
+ * zero Linear coefficient of a constant piece gives +-Inf or NaN, an exact cancellation 0
+ * (funPieceListLog.cpp:563) -- and all of it is ordinary there: the special values by selects
+ * (what psd_log_slow returns for them), the record only for positive subnormals. */
+PSD_HD static inline double PSD_FN(psd_log_wild_nb)(double x, int *rare) {
+  const uint64_t hx = psd_d2u(x);
+  const int odd = !((uint32_t)(hx >> 32) - 0x00100000u < 0x7fe00000u);
+  double y = PSD_FN(psd_log_core)(hx, 0);
+  y = (x < 0.0) ? psd_u2d(0x7ff8000000000000ULL) : y;
+  y = (x == 0.0) ? -PSD_INFINITY : y;
+  y = (x == PSD_INFINITY) ? x : y;
+  y = (x != x) ? x + x : y;
+  *rare |= odd && x > 0.0 && x < 0x1p-1022;
+  return y;
 }

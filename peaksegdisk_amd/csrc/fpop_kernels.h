@@ -240,18 +240,18 @@ PSD_D int chain_step(const DeviceArgs &a, ArenaCursor &cur, unsigned long long f
   int nm = 0;
   /* operations out of line; in LDS the versions specialised for short functions when they
    * apply */
+  /* (the specialised versions answer -WERR_SERIAL when they met a rare exp / log argument:
+   * their arithmetic has no branch for those, the general versions do) */
   if (chain == 0) {
-    if (L::in_lds && n_other <= WAVE) {
-      nm = min_less_small_wave(other_prev, n_other, mlist, cap, sc, t - 1, pen_term);
-    } else {
-      nm = min_less_wave(other_prev, n_other, mlist, cap, sc, t - 1, pen_term);
-    }
+    nm = -WERR_SERIAL;
+    if (L::in_lds && n_other <= WAVE)
+      nm = uniform_i(min_less_small_wave(other_prev, n_other, mlist, cap, sc, t - 1, pen_term));
+    if (nm == -WERR_SERIAL) nm = min_less_wave(other_prev, n_other, mlist, cap, sc, t - 1, pen_term);
   } else if (t >= 2) {
-    if (L::in_lds && n_other <= WAVE) {
-      nm = min_more_small_wave(other_prev, n_other, mlist, cap, sc, t - 1);
-    } else {
-      nm = min_more_wave(other_prev, n_other, mlist, cap, sc, t - 1);
-    }
+    nm = -WERR_SERIAL;
+    if (L::in_lds && n_other <= WAVE)
+      nm = uniform_i(min_more_small_wave(other_prev, n_other, mlist, cap, sc, t - 1));
+    if (nm == -WERR_SERIAL) nm = min_more_wave(other_prev, n_other, mlist, cap, sc, t - 1);
   }
   nm = uniform_i(nm); /* return values of out-of-line functions arrive in a VGPR */
   if (nm < 0) return nm;
@@ -297,15 +297,19 @@ PSD_D int chain_step_fast(const DeviceArgs &a, ArenaCursor &cur, unsigned long l
                           double cum_weight_prev, double w, int coverage, double cum_weight) {
   PSD_ASSUME(n_other <= FAST_MAX_OTHER && n_own <= FAST_MAX_OWN);
   int nm;
+  MathFast mth; /* exp / log without their rare-argument branches; one test at the end */
   if (chain == 0) {
-    nm = min_less_impl<true>(other_prev, n_other, mlist, LDS_CAP, sc, t - 1, pen_term);
+    nm = min_less_impl<true>(other_prev, n_other, mlist, LDS_CAP, sc, t - 1, pen_term, mth);
   } else {
-    nm = min_more_impl<true>(other_prev, n_other, mlist, LDS_CAP, sc, t - 1);
+    nm = min_more_impl<true>(other_prev, n_other, mlist, LDS_CAP, sc, t - 1, mth);
   }
-  if (nm < 0) return nm;
+  /* (an error may itself be the consequence of a rare argument's unspecified value: the
+   * general path decides) */
+  if (nm < 0) return ballot(mth.rare != 0) ? -WERR_SERIAL : nm;
   if (nm > 32) return -WERR_OVERFLOW; /* cannot happen: at most 2 pieces per input piece */
   const LdsList f1 = chain == 0 ? mlist : mlist.shifted(LDS_CAP - nm);
-  int n_new = min_env_impl<HELP, true>(f1, nm, own_prev, n_own, own_new, LDS_CAP, sc, chain);
+  int n_new = min_env_impl<HELP, true>(f1, nm, own_prev, n_own, own_new, LDS_CAP, sc, chain, mth);
+  if (ballot(mth.rare != 0)) return -WERR_SERIAL; /* the general path redoes the data point */
   if (n_new < 0) return n_new;
   PSD_PROF_T0();
   wave_sync();
@@ -392,7 +396,8 @@ PSD_COLD_DEV void helper_hbm_op(const DeviceArgs &a, int chain, int op) {
     P.c.Linear = P.c.Log = P.c.Constant = 0.0;
     P.mn = P.mx = P.lc = P.rc = P.om = P.mu = P.muc = P.oc2 = 0.0;
     P.cls = CLS_STORE;
-    piece_costs_wave(global_list(a, p, uniform_i(m.h_arg[1])), uniform_i(m.h_arg[2]), s, P, 1, 2);
+    MathFull mth;
+    piece_costs_wave(global_list(a, p, uniform_i(m.h_arg[1])), uniform_i(m.h_arg[2]), s, P, mth, 1, 2);
   } else {
     const GlobalList f1 = global_list(a, p, uniform_i(m.h_arg[1])).shifted(uniform_i(m.h_arg[2]));
     const int n1 = uniform_i(m.h_arg[3]);
@@ -413,11 +418,13 @@ PSD_COLD_DEV void helper_hbm_op(const DeviceArgs &a, int chain, int op) {
 }
 PSD_NOINLINE int min_less_coop_wave(GlobalList in, int n, GlobalList out, int cap, GlobalScratch s,
                                     int data_i_out, double add_const, int chain, int p, int id) {
-  return min_less_impl<false, true>(in, n, out, cap, s, data_i_out, add_const, chain, p, id);
+  MathFull mth;
+  return min_less_impl<false, true>(in, n, out, cap, s, data_i_out, add_const, mth, chain, p, id);
 }
 PSD_NOINLINE int min_more_coop_wave(GlobalList in, int n, GlobalList out, int cap, GlobalScratch s,
                                     int data_i_out, int chain, int p, int id) {
-  return min_more_impl<false, true>(in, n, out, cap, s, data_i_out, chain, p, id);
+  MathFull mth;
+  return min_more_impl<false, true>(in, n, out, cap, s, data_i_out, mth, chain, p, id);
 }
 PSD_NOINLINE int min_env_coop_wave(GlobalList f1, int n1, GlobalList f2, int n2, GlobalList out,
                                    int cap, GlobalScratch s, int chain, int p, int id1, int off1,

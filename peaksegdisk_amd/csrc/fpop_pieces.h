@@ -61,9 +61,11 @@ PSD_D double d_log(double x) { return psd_log(x); }
 #if defined(PSD_MATH_VK) && defined(__HIP_DEVICE_COMPILE__)
 PSD_D double d_exp_nb(double x, int &rare) { return psd_exp_nb_vk(x, &rare); }
 PSD_D double d_log_nb(double x, int &rare) { return psd_log_nb_vk(x, &rare); }
+PSD_D double d_log_wild_nb(double x, int &rare) { return psd_log_wild_nb_vk(x, &rare); }
 #else
 PSD_D double d_exp_nb(double x, int &rare) { return psd_exp_nb(x, &rare); }
 PSD_D double d_log_nb(double x, int &rare) { return psd_log_nb(x, &rare); }
+PSD_D double d_log_wild_nb(double x, int &rare) { return psd_log_wild_nb(x, &rare); }
 #endif
 #if defined(PSD_MATH_VK) && defined(__HIP_DEVICE_COMPILE__)
 PSD_D void d_exp2(double x0, double x1, double &y0, double &y1) { psd_exp2_vk(x0, x1, &y0, &y1); }
@@ -114,6 +116,73 @@ PSD_D double get_cost_e(const Coef &c, double log_mean, double exp_log_mean) {
   double log_term = (c.Log == 0) ? 0.0 : c.Log * log_mean;
   return linear_term + log_term + c.Constant;
 }
+
+/* How a step evaluates exp / log.  NB = false: the complete functions, each with its branch to
+ * the rare-argument path.  NB = true (the inlined fast path of a step): without those branches
+ * -- a branch ends a basic block, and a wave on its own can only overlap the ~110 cycles of a
+ * table look-up with work of the same block -- and with a record of having met a rare argument;
+ * the step then ends with ONE test of that record and is redone by the general path, complete
+ * functions and all (never on real data: |log-mean| > 708, means <= 0, NaN).  Removing every
+ * such branch is worth 3.8 % of the forward kernel (profiles/r03/ab_rare_branches.log). */
+template <bool NB>
+struct StepMath {
+  int rare;
+#ifdef PSD_FORCE_RARE /* tests only: every step (and helper round) takes the redo path */
+  PSD_M StepMath() : rare(NB ? 1 : 0) {}
+#else
+  PSD_M StepMath() : rare(0) {}
+#endif
+  PSD_M double exp(double x) {
+    if (NB) return d_exp_nb(x, rare);
+    return d_exp(x);
+  }
+  PSD_M double log(double x) {
+    if (NB) return d_log_nb(x, rare);
+    return d_log(x);
+  }
+  /* log of a quotient that may be +-Inf, NaN or 0 as a matter of course (psd_log_wild_nb) */
+  PSD_M double log_wild(double x) {
+    if (NB) return d_log_wild_nb(x, rare);
+    return d_log(x);
+  }
+  PSD_M void exp2(double x0, double x1, double &y0, double &y1) {
+    if (NB) {
+      y0 = d_exp_nb(x0, rare);
+      y1 = d_exp_nb(x1, rare);
+    } else {
+      d_exp2(x0, x1, y0, y1);
+    }
+  }
+  PSD_M void log2(double x0, double x1, double &y0, double &y1) {
+    if (NB) {
+      y0 = d_log_nb(x0, rare);
+      y1 = d_log_nb(x1, rare);
+    } else {
+      d_log2(x0, x1, y0, y1);
+    }
+  }
+  PSD_M void exp2_log(double x0, double x1, double z, double &y0, double &y1, double &lz) {
+    if (NB) {
+      y0 = d_exp_nb(x0, rare);
+      y1 = d_exp_nb(x1, rare);
+      lz = d_log_nb(z, rare);
+    } else {
+      d_exp2_log(x0, x1, z, y0, y1, lz);
+    }
+  }
+  /* getCost (fpl:206-222), as get_cost() */
+  PSD_M double cost(const Coef &c, double log_mean) {
+    const bool at_zero_mean = log_mean == -PSD_INF;
+    double e = exp(at_zero_mean ? 0.0 : log_mean);
+    double linear_term = at_zero_mean ? 0.0 : c.Linear * e;
+    double log_term = (c.Log == 0) ? 0.0 : c.Log * log_mean;
+    return linear_term + log_term + c.Constant;
+  }
+  /* the final log of get_larger_root */
+  PSD_M int *rare_out() { return NB ? &rare : nullptr; }
+};
+typedef StepMath<false> MathFull;
+typedef StepMath<true> MathFast;
 
 /* The optimum of a piece, shared by has_two_roots / get_smaller_root / get_larger_root /
  * argmin (fpl:37-40,70-71,134-135,203): every one of them starts from the same
@@ -192,7 +261,8 @@ PSD_COLD_DEV double larger_root_full(Coef c, double optimal_mean, double optimal
 /* fpl:69-127: larger root, returned as a log-mean.
  * right_cost = getCost(max_log_mean), supplied by the caller. */
 PSD_D double get_larger_root(const Coef &c, const PieceOpt &o, double max_log_mean,
-                             double right_cost, double equals, int *steps_out = nullptr) {
+                             double right_cost, double equals, int *steps_out = nullptr,
+                             int *rare_out = nullptr) {
   double optimal_mean = o.mean;
   double optimal_cost = o.cost2;
   if ((optimal_cost < right_cost && right_cost < equals) ||
@@ -240,6 +310,7 @@ PSD_D double get_larger_root(const Coef &c, const PieceOpt &o, double max_log_me
   } while (NEWTON_EPSILON < absd(candidate_cost));
 #endif
   if (steps_out) *steps_out = step;
+  if (rare_out) return d_log_nb(candidate_root, *rare_out); /* (see StepMath) */
   return d_log(candidate_root);
 }
 

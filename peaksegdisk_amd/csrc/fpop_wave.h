@@ -380,8 +380,8 @@ struct LanePiece {
 /* Shared first half of min-less / min-more: per piece, the costs at both ends and the
  * optimum (fpl:245-246,310-311 / 469-470,483-485); kept in scratch for every piece and in
  * registers for piece `lane`. */
-template <class L, class S>
-PSD_D void piece_costs_wave(const L &in, int n, const S &s, LanePiece &P, int chunk0 = 0,
+template <class L, class S, class M>
+PSD_D void piece_costs_wave(const L &in, int n, const S &s, LanePiece &P, M &mth, int chunk0 = 0,
                             int stride = 1) {
   const int lane = lane_id();
   /* chunks chunk0, chunk0 + stride, ...: two waves share a long function (HOP_HBM_COSTS) */
@@ -398,13 +398,13 @@ PSD_D void piece_costs_wave(const L &in, int n, const S &s, LanePiece &P, int ch
       PieceOpt o = {0.0, 0.0, 0.0, 0.0};
       if (has_opt) o.mean = argmin_mean(c);
       double e_mn, e_mx, l_om;
-      d_exp2_log(mn == -PSD_INF ? 0.0 : mn, mx == -PSD_INF ? 0.0 : mx, has_opt ? o.mean : 1.0,
-                 e_mn, e_mx, l_om);
+      mth.exp2_log(mn == -PSD_INF ? 0.0 : mn, mx == -PSD_INF ? 0.0 : mx, has_opt ? o.mean : 1.0,
+                   e_mn, e_mx, l_om);
       double lc = get_cost_e(c, mn, e_mn);
       double rc = get_cost_e(c, mx, e_mx);
       if (has_opt) {
         o.log_mean = l_om;
-        o.cost = get_cost(c, o.log_mean);
+        o.cost = mth.cost(c, o.log_mean);
         double loss_without_log_term = c.Linear * o.mean + c.Constant; /* fpl:52-61 */
         o.cost2 = loss_without_log_term + o.log_mean * c.Log;
       }
@@ -449,14 +449,15 @@ PSD_D bool coop_piece_costs(const L &in, int n, const S &s, LanePiece &P, int ch
     m.h_arg[2] = n;
   }
   mail_post(chain, HOP_HBM_COSTS);
-  piece_costs_wave(in, n, s, P, 0, 2);
+  MathFull mth;
+  piece_costs_wave(in, n, s, P, mth, 0, 2);
   return mail_wait(chain);
 }
 #endif
 /* COOP: the function is list coop_id of spill slot coop_p and the chain's helper wave takes
  * half of the chunks (latency build, lists in HBM). */
-template <bool COOP = false, class L, class S>
-PSD_D bool min_less_pre(const L &in, int n, const S &s, LanePiece &P, int coop_chain = 0,
+template <bool COOP = false, class L, class S, class M>
+PSD_D bool min_less_pre(const L &in, int n, const S &s, LanePiece &P, M &mth, int coop_chain = 0,
                         int coop_p = 0, int coop_id = 0) {
   const int lane = lane_id();
   bool ok = true;
@@ -466,7 +467,7 @@ PSD_D bool min_less_pre(const L &in, int n, const S &s, LanePiece &P, int coop_c
   } else
 #endif
   {
-    piece_costs_wave(in, n, s, P);
+    piece_costs_wave(in, n, s, P, mth);
   }
   /* what the walk does with piece i when it reaches it in search mode */
   for (int base = 0; base < n; base += WAVE) {
@@ -508,8 +509,8 @@ PSD_D bool min_less_pre(const L &in, int n, const S &s, LanePiece &P, int coop_c
 }
 
 /* First pass of min-more, as min_less_pre. */
-template <bool COOP = false, class L, class S>
-PSD_D bool min_more_pre(const L &in, int n, const S &s, LanePiece &P, int coop_chain = 0,
+template <bool COOP = false, class L, class S, class M>
+PSD_D bool min_more_pre(const L &in, int n, const S &s, LanePiece &P, M &mth, int coop_chain = 0,
                         int coop_p = 0, int coop_id = 0) {
   const int lane = lane_id();
   bool ok = true;
@@ -519,7 +520,7 @@ PSD_D bool min_more_pre(const L &in, int n, const S &s, LanePiece &P, int coop_c
   } else
 #endif
   {
-    piece_costs_wave(in, n, s, P);
+    piece_costs_wave(in, n, s, P, mth);
   }
   for (int base = 0; base < n; base += WAVE) {
     int i = base + lane;
@@ -556,9 +557,10 @@ PSD_D bool min_more_pre(const L &in, int n, const S &s, LanePiece &P, int coop_c
 /* min-less: out(x) = min_{y<=x} in(y).  All output pieces get data_i = data_i_out (the
  * driver's set_prev_seg_end) and Constant += add_const (its add(0,0,penalty/cum_weight_prev),
  * PeakSegFPOPLog.cpp:290-296). */
-template <bool SMALL, bool COOP = false, class L, class S>
+template <bool SMALL, bool COOP = false, class L, class S, class M>
 PSD_D int min_less_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
-                        double add_const_, int coop_chain = 0, int coop_p = 0, int coop_id = 0) {
+                        double add_const_, M &mth, int coop_chain = 0, int coop_p = 0,
+                        int coop_id = 0) {
   const L in = in_.uniformed(), out = out_.uniformed();
   const S s = s_.uniformed();
   const int n = uniform_i(n_), cap = uniform_i(cap_), data_i_out = uniform_i(data_i_out_);
@@ -572,7 +574,7 @@ PSD_D int min_less_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
   P.mn = P.mx = P.lc = P.rc = P.om = P.mu = P.muc = P.oc2 = 0.0;
   P.cls = CLS_STORE;
   PSD_PROF_T0();
-  if (!min_less_pre<COOP>(in, n, s, P, coop_chain, coop_p, coop_id)) return -WERR_HELPER;
+  if (!min_less_pre<COOP>(in, n, s, P, mth, coop_chain, coop_p, coop_id)) return -WERR_HELPER;
   PSD_PROF_ADD(PROF_PRE);
   /* uniform reads of piece j: registers of lane j when the function fits one wave */
   auto cls_at = [&](int j) -> int { return small ? rdlane_i(P.cls, j) : s.cls(j); };
@@ -853,8 +855,8 @@ PSD_D int min_less_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
 /* ------------------------------------------------------------------------------------- */
 /* min-more: out(x) = min_{y>=x} in(y).  The reference builds the list with emplace_front;
  * here pieces are written downwards from out[cap-1]: the result is out[cap-n .. cap). */
-template <bool SMALL, bool COOP = false, class L, class S>
-PSD_D int min_more_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
+template <bool SMALL, bool COOP = false, class L, class S, class M>
+PSD_D int min_more_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_, M &mth,
                         int coop_chain = 0, int coop_p = 0, int coop_id = 0) {
   const L in = in_.uniformed(), out = out_.uniformed();
   const S s = s_.uniformed();
@@ -867,7 +869,7 @@ PSD_D int min_more_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
   P.mn = P.mx = P.lc = P.rc = P.om = P.mu = P.muc = P.oc2 = 0.0;
   P.cls = CLS_STORE;
   PSD_PROF_T0();
-  if (!min_more_pre<COOP>(in, n, s, P, coop_chain, coop_p, coop_id)) return -WERR_HELPER;
+  if (!min_more_pre<COOP>(in, n, s, P, mth, coop_chain, coop_p, coop_id)) return -WERR_HELPER;
   PSD_PROF_ADD(PROF_PRE);
   auto cls_at = [&](int j) -> int { return small ? rdlane_i(P.cls, j) : s.cls(j); };
   auto mu_at = [&](int j) -> double { return small ? rdlane_d(P.mu, j) : s.mu(j); };
@@ -940,10 +942,10 @@ PSD_D int min_more_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
       PSD_PROF_SUB(PROF_S_LOAD);
       if (tj >= 0) {
         if (c.Log == 0) {
-          sp_mu = d_log((level - c.Constant) / c.Linear); /* fpl:563 */
+          sp_mu = mth.log_wild((level - c.Constant) / c.Linear); /* fpl:563 */
         } else {
           if (has_two_roots(c, o, level)) {
-            sp_mu = get_larger_root(c, o, t_mx, t_rc, level, &sp_steps);
+            sp_mu = get_larger_root(c, o, t_mx, t_rc, level, &sp_steps, mth.rare_out());
           }
         }
         inside = t_mn < sp_mu && sp_mu < t_mx;
@@ -1406,10 +1408,10 @@ PSD_D void env_interval_at(const L &f1, int n1, const L &f2, int n2, int i1, int
  * the same time (predicated phases) instead of each lane walking its own branch of
  * push_min_pieces -- a wave otherwise executes the union of all branches one after another.
  * The arithmetic per lane is identical to env_interval(). */
-template <bool HELP>
+template <bool HELP, class M>
 PSD_D void env_classify_lanes(bool valid, const Coef &c1, const Coef &c2, double a, double b,
                               bool same_at_left, bool same_at_right, Cands &out, int chain,
-                              int &err) {
+                              int &err, M &mth) {
   out.n = 0;
   out.first = 0;
   out.x1 = out.x2 = 0.0;
@@ -1458,13 +1460,13 @@ PSD_D void env_classify_lanes(bool valid, const Coef &c1, const Coef &c2, double
   bool two_roots = false;
 #ifndef PSD_NO_PAIRED_MATH
   if (ballot(act)) {
-    d_exp2((act && a != -PSD_INF) ? a : 0.0, act ? b : 0.0, ea, eb);
+    mth.exp2((act && a != -PSD_INF) ? a : 0.0, act ? b : 0.0, ea, eb);
     if (a == -PSD_INF) ea = 0.0; /* exp(-Inf) */
     double log_mid;
-    d_log2(act ? (eb + ea) / 2 : 1.0, need_l ? larg : 1.0, log_mid, lres);
+    mth.log2(act ? (eb + ea) / 2 : 1.0, need_l ? larg : 1.0, log_mid, lres);
     if (!need_l) lres = 0.0;
     double e_mid, e_opt;
-    d_exp2(log_mid == -PSD_INF ? 0.0 : log_mid, (rootp && lres != -PSD_INF) ? lres : 0.0, e_mid,
+    mth.exp2(log_mid == -PSD_INF ? 0.0 : log_mid, (rootp && lres != -PSD_INF) ? lres : 0.0, e_mid,
            e_opt);
     if (act) cost_diff_mid = get_cost_e(d, log_mid, e_mid);
     if (!act) ea = eb = 0.0;
@@ -1473,13 +1475,13 @@ PSD_D void env_classify_lanes(bool valid, const Coef &c1, const Coef &c2, double
   PSD_PROF_ADD(PROF_C_MID);
 #else
   if (act) {
-    ea = d_exp(a);
-    eb = d_exp(b);
-    cost_diff_mid = get_cost(d, d_log((eb + ea) / 2));
+    ea = mth.exp(a);
+    eb = mth.exp(b);
+    cost_diff_mid = mth.cost(d, mth.log((eb + ea) / 2));
   }
   PSD_PROF_ADD(PROF_C_MID);
-  if (need_l) lres = d_log(larg);
-  if (rootp) o.cost = get_cost(d, lres);
+  if (need_l) lres = mth.log(larg);
+  if (rootp) o.cost = mth.cost(d, lres);
 #endif
   if (rootp) {
     cost_diff_left = get_cost_e(d, a, ea);
@@ -1509,8 +1511,8 @@ PSD_D void env_classify_lanes(bool valid, const Coef &c1, const Coef &c2, double
 #endif
   if (EARLY_TAIL && ballot(neither && two_roots)) {
     const bool on = neither && two_roots;
-    e_smaller = d_exp(on ? smaller_log_mean : 0.0);
-    cost_before_smaller = get_cost(d, d_log(on ? (ea + e_smaller) / 2 : 1.0));
+    e_smaller = mth.exp(on ? smaller_log_mean : 0.0);
+    cost_before_smaller = mth.cost(d, mth.log(on ? (ea + e_smaller) / 2 : 1.0));
     if (!on) e_smaller = 0.0;
   }
 #ifdef PSD_HELPER_WAVES
@@ -1527,14 +1529,14 @@ PSD_D void env_classify_lanes(bool valid, const Coef &c1, const Coef &c2, double
   } else
 #endif
   {
-    if (two_roots) larger_log_mean = get_larger_root(d, o, b, cost_diff_right, 0.0, &it_large);
+    if (two_roots) larger_log_mean = get_larger_root(d, o, b, cost_diff_right, 0.0, &it_large, mth.rare_out());
   }
   (void)root_posted;
   PSD_PROF_ADD(PROF_C_LARGE);
   PSD_PROF_ITERS(PROF_IT_SMALL, it_small);
   PSD_PROF_ITERS(PROF_IT_LARGE, it_large);
   /* phase G, the part that needs both roots */
-  if (!EARLY_TAIL && neither && two_roots) e_smaller = d_exp(smaller_log_mean);
+  if (!EARLY_TAIL && neither && two_roots) e_smaller = mth.exp(smaller_log_mean);
   double first_log_mean = PSD_INF, second_log_mean = PSD_INF;
   if (neither && two_roots) {
     bool larger_inside = a < larger_log_mean && larger_log_mean < b;
@@ -1559,22 +1561,22 @@ PSD_D void env_classify_lanes(bool valid, const Coef &c1, const Coef &c2, double
   const double x_other =
       two ? (first_log_mean + second_log_mean) / 2 : (b + first_log_mean) / 2;
   double cost_diff_other = 0.0;
-  if (need_other) cost_diff_other = get_cost(d, x_other);
+  if (need_other) cost_diff_other = mth.cost(d, x_other);
   double cost_diff_before = 0.0;
   if (EARLY_TAIL) {
     if (need_before) cost_diff_before = cost_before_smaller;
     /* the larger root is the first crossing: exp(first crossing) and the cost before it anew */
     const bool redo = need_before && first_log_mean != smaller_log_mean;
     if (ballot(redo)) {
-      const double e_first = d_exp(redo ? first_log_mean : 0.0);
-      const double c_before = get_cost(d, d_log(redo ? (ea + e_first) / 2 : 1.0));
+      const double e_first = mth.exp(redo ? first_log_mean : 0.0);
+      const double c_before = mth.cost(d, mth.log(redo ? (ea + e_first) / 2 : 1.0));
       if (redo) cost_diff_before = c_before;
     }
   } else {
     /* exp(first crossing) unless it is the value already computed */
     double e_first = e_smaller;
-    if (need_before && first_log_mean != smaller_log_mean) e_first = d_exp(first_log_mean);
-    if (need_before) cost_diff_before = get_cost(d, d_log((ea + e_first) / 2));
+    if (need_before && first_log_mean != smaller_log_mean) e_first = mth.exp(first_log_mean);
+    if (need_before) cost_diff_before = mth.cost(d, mth.log((ea + e_first) / 2));
   }
 
   PSD_PROF_ADD(PROF_C_TAIL);
@@ -1704,6 +1706,30 @@ PSD_D bool bit_identical(const Coef &last, double last_prv, int last_di, const C
 }
 
 #ifdef PSD_HELPER_WAVES
+/* HOP_ROOT: the larger roots of the lanes flagged by the chain wave.  Returns nonzero in a lane
+ * that met a rare exp / log argument (NB only). */
+template <bool NB>
+PSD_D int helper_root_lanes(Mail &m, int lane) {
+  StepMath<NB> mth;
+  if (m.flags[lane] & 1) {
+    const Coef d = {m.d_lin[lane], m.d_log[lane], m.d_con[lane]};
+    /* the optimum of the difference piece exactly as env_classify_lanes derives it */
+    PieceOpt o;
+    o.mean = -d.Log / d.Linear;
+    o.log_mean = mth.log(o.mean);
+    o.cost = mth.cost(d, o.log_mean);
+    double loss_without_log_term = d.Linear * o.mean + d.Constant;
+    o.cost2 = loss_without_log_term + o.log_mean * d.Log;
+    const double b = m.b[lane];
+    double root = PSD_INF;
+    /* NaN as the right-end cost disables the early exit: the main wave applies it */
+    if (has_two_roots(d, o, 0.0))
+      root = get_larger_root(d, o, b, __builtin_nan(""), 0.0, nullptr, mth.rare_out());
+    m.res_large[lane] = root;
+  }
+  return mth.rare;
+}
+
 /* the helper's share of an operation on lists in HBM (fpop_kernels.h) */
 PSD_COLD_DEV void helper_hbm_op(const DeviceArgs &a, int chain, int op);
 /* Body of a helper wave: serve the main wave of `chain` until HOP_EXIT. */
@@ -1725,22 +1751,8 @@ PSD_D void helper_loop(int chain, const DeviceArgs &a) {
     if (op == HOP_BARRIER) {
       __syncthreads();
     } else if (op == HOP_ROOT) {
-      if (m.flags[lane] & 1) {
-        const Coef d = {m.d_lin[lane], m.d_log[lane], m.d_con[lane]};
-        /* the optimum of the difference piece exactly as env_classify_lanes derives it */
-        PieceOpt o;
-        o.mean = -d.Log / d.Linear;
-        o.log_mean = d_log(o.mean);
-        o.cost = get_cost(d, o.log_mean);
-        double loss_without_log_term = d.Linear * o.mean + d.Constant;
-        o.cost2 = loss_without_log_term + o.log_mean * d.Log;
-        const double b = m.b[lane];
-        double root = PSD_INF;
-        /* NaN as the right-end cost disables the early exit: the main wave applies it */
-        if (has_two_roots(d, o, 0.0)) root = get_larger_root(d, o, b, __builtin_nan(""), 0.0);
-        m.res_large[lane] = root;
-
-      }
+      /* without the rare-argument branches first; the complete functions if one was met */
+      if (ballot(helper_root_lanes<true>(m, lane) != 0)) (void)helper_root_lanes<false>(m, lane);
     } else if (op >= HOP_HBM_COSTS) {
       helper_hbm_op(*a.self, chain, op);
     }
@@ -1795,8 +1807,9 @@ PSD_NOINLINE int min_env_serial(L f1_, int n1_, L f2_, int n2_, L out_, int cap_
 }
 
 /* min-envelope: out = pointwise min(f1, f2). */
-template <bool HELP, bool SMALL, class L, class S>
-PSD_D int min_env_impl(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, int chain_) {
+template <bool HELP, bool SMALL, class L, class S, class M>
+PSD_D int min_env_impl(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, int chain_,
+                       M &mth) {
   const int chain = uniform_i(chain_);
   const L f1 = f1_.uniformed(), f2 = f2_.uniformed(), out = out_.uniformed();
   const S s = s_.uniformed();
@@ -1945,7 +1958,7 @@ PSD_D int min_env_impl(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, i
     }
     env_neighbour_flags(f1, f2, s, k, K, valid, valid && same_funs(c1, c2), sl, sr);
     PSD_PROF_ADD(PROF_C_LOAD);
-    env_classify_lanes<HELP>(valid && err == 0, c1, c2, ia, ib, sl, sr, cd, chain, err);
+    env_classify_lanes<HELP>(valid && err == 0, c1, c2, ia, ib, sl, sr, cd, chain, err, mth);
     PSD_PROF_ADD(PROF_CLASSIFY);
     /* first / last candidate of this lane */
     const int src0 = cd.first, src1 = cd.first ^ 1; /* the third piece has source src0 again */
@@ -2182,7 +2195,9 @@ PSD_D void env_coop_classify(const L &f1, int n1, const L &f2, int n2, const S &
   env_coop_load(f1, n1, f2, n2, s, k, valid, e);
   bool sl = false, sr = false;
   env_neighbour_flags(f1, f2, s, k, K, valid, valid && same_funs(e.c1, e.c2), sl, sr);
-  env_classify_lanes<false>(valid && e.err == 0, e.c1, e.c2, e.ia, e.ib, sl, sr, e.cd, chain, e.err);
+  MathFull mth;
+  env_classify_lanes<false>(valid && e.err == 0, e.c1, e.c2, e.ia, e.ib, sl, sr, e.cd, chain, e.err,
+                            mth);
 }
 
 /* Which chunks of merged intervals the helper classifies: three of every five.  The chain wave
@@ -2396,30 +2411,41 @@ PSD_D int min_env_coop(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, i
 template <class L, class S>
 PSD_NOINLINE int min_less_wave(L in, int n, L out, int cap, S s, int data_i_out,
                                double add_const) {
-  return min_less_impl<false>(in, n, out, cap, s, data_i_out, add_const);
+  MathFull mth;
+  return min_less_impl<false>(in, n, out, cap, s, data_i_out, add_const, mth);
 }
 template <class L, class S>
 PSD_NOINLINE int min_more_wave(L in, int n, L out, int cap, S s, int data_i_out) {
-  return min_more_impl<false>(in, n, out, cap, s, data_i_out);
+  MathFull mth;
+  return min_more_impl<false>(in, n, out, cap, s, data_i_out, mth);
 }
 template <bool HELP, class L, class S>
 PSD_NOINLINE int min_env_wave(L f1, int n1, L f2, int n2, L out, int cap, S s, int chain) {
-  return min_env_impl<HELP, false>(f1, n1, f2, n2, out, cap, s, chain);
+  MathFull mth;
+  return min_env_impl<HELP, false>(f1, n1, f2, n2, out, cap, s, chain, mth);
 }
 /* the same, specialised for n <= 64 (min_env: n1, n2 <= 32): what the throughput build, whose
- * operations all stay out of line, calls for nearly every data point */
+ * operations all stay out of line, calls for nearly every data point.  Their exp / log come
+ * without the rare-argument branches (StepMath): -WERR_SERIAL when such an argument was met,
+ * and the caller takes the general version above. */
 template <class L, class S>
 PSD_NOINLINE int min_less_small_wave(L in, int n, L out, int cap, S s, int data_i_out,
                                      double add_const) {
-  return min_less_impl<true>(in, n, out, cap, s, data_i_out, add_const);
+  MathFast mth;
+  const int r = min_less_impl<true>(in, n, out, cap, s, data_i_out, add_const, mth);
+  return ballot(mth.rare != 0) ? -WERR_SERIAL : r;
 }
 template <class L, class S>
 PSD_NOINLINE int min_more_small_wave(L in, int n, L out, int cap, S s, int data_i_out) {
-  return min_more_impl<true>(in, n, out, cap, s, data_i_out);
+  MathFast mth;
+  const int r = min_more_impl<true>(in, n, out, cap, s, data_i_out, mth);
+  return ballot(mth.rare != 0) ? -WERR_SERIAL : r;
 }
 template <bool HELP, class L, class S>
 PSD_NOINLINE int min_env_small_wave(L f1, int n1, L f2, int n2, L out, int cap, S s, int chain) {
-  return min_env_impl<HELP, true>(f1, n1, f2, n2, out, cap, s, chain);
+  MathFast mth;
+  const int r = min_env_impl<HELP, true>(f1, n1, f2, n2, out, cap, s, chain, mth);
+  return ballot(mth.rare != 0) ? -WERR_SERIAL : r;
 }
 
 }  // namespace PSD_VARIANT
