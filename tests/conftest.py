@@ -22,6 +22,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _flush_c_stdio():
+    """The oracle prints the reference's messages with printf: flush them into the test's own
+    captured output instead of leaving them for process exit (after pytest's summary)."""
+    yield
+    ctypes.CDLL(None).fflush(None)
+
+
 def _build_oracle():
     subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
 

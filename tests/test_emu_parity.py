@@ -146,7 +146,7 @@ def test_emu_sequential_envelope_replay(oracle_det, tmp_path):
 
 
 def test_emu_varied_data_shapes(psd, oracle_det, tmp_path, monkeypatch):
-    gp.test_varied_data_shapes(psd, oracle_det, tmp_path, monkeypatch, 4, 7)
+    gp.test_varied_data_shapes(psd, oracle_det, tmp_path, monkeypatch, 3, 7)
 
 
 def test_emu_grid_properties_small(psd):
@@ -187,7 +187,7 @@ def test_emu_resident_search_exact_sequence(psd, oracle_det, known_answers, tmp_
 
 
 def test_emu_search_batch_equals_single_searches(psd, tmp_path):
-    gp2.test_search_batch_equals_single_searches(psd, tmp_path, n_bins=600, with_mono=False)
+    gp2.test_search_batch_equals_single_searches(psd, tmp_path, n_bins=400, with_mono=False)
 
 
 def test_emu_dir_batch_cache_and_timing(psd, oracle_det, tmp_path):
@@ -199,7 +199,7 @@ def test_emu_spill_pool_and_arena_regrowth(psd, oracle_det, tmp_path, monkeypatc
 
 
 def test_emu_checkpointed_store(psd, oracle_det, tmp_path, monkeypatch):
-    gp2.test_checkpointed_store_equals_full_store(psd, oracle_det, tmp_path, monkeypatch, 1200,
+    gp2.test_checkpointed_store_equals_full_store(psd, oracle_det, tmp_path, monkeypatch, 800,
                                                   (16, 3000))
 
 
@@ -209,7 +209,7 @@ def test_emu_checkpointed_store_limits(psd, tmp_path, monkeypatch):
 
 
 def test_emu_mixed_launch(psd, tmp_path, monkeypatch):
-    gp2.test_mixed_launch_of_unequal_contigs(psd, tmp_path, monkeypatch, 500, 40, 63)
+    gp2.test_mixed_launch_of_unequal_contigs(psd, tmp_path, monkeypatch, 300, 25, 63)
 
 
 def test_emu_solve_grid(psd, tmp_path):
@@ -241,4 +241,4 @@ def test_emu_batch_with_duplicate_problems(psd, oracle_det, tmp_path):
 
 def test_emu_arena_regrowth_resumes(psd, oracle_det, tmp_path, monkeypatch):
     gp3.test_arena_regrowth_resumes_instead_of_repeating(psd, oracle_det, tmp_path, monkeypatch,
-                                                         n_bins=1500)
+                                                         n_bins=1000)

@@ -191,14 +191,14 @@ def test_bench_launches_its_ranks_as_the_driver_does():
     """`python bench.py --gpus 2 --steps K --warmup W` with no torchrun environment must run
     TWO ranks and report n_gpus == 2 (round 1 ignored --gpus)."""
     env = {"PSD_BENCH_BACKEND": "gloo", "PSD_BENCH_TEST_LIB": _emu_lib()}
-    p = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--bins", "300",
+    p = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--bins", "150",
                     "--penalties", "3", "--no-cpu"], env)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
-    assert abs(d["value"] - 300 * 3 * 2 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]
+    assert abs(d["value"] - 150 * 3 * 2 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]
     # configs[3] as a bench mode: fixed work dealt over the ranks
     p = _run_bench(["--gpus", "2", "--mode", "grid", "--steps", "1", "--warmup", "0",
                     "--grid-contigs", "5", "--grid-scale", "0.002", "--penalties", "3"], env)
