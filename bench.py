@@ -334,7 +334,10 @@ def main():
                  "hbm_bytes_resident": stats.get("hbm_bytes"),
                  # 0: every cost function stored; K: the checkpointed store (picked when the
                  # full store of rank 0's share would not fit its HBM)
-                 "checkpoint_interval": stats.get("checkpoint_interval")}
+                 "checkpoint_interval": stats.get("checkpoint_interval"),
+                 "rank0_phase_seconds": {k: round(stats[k], 3) for k in
+                                         ("create_s", "solve_s", "tables_s", "close_s")
+                                         if k in stats}}
 
     if rank == 0:
         units = units_per_step * args.steps

@@ -39,8 +39,9 @@ extern "C" {
  *                               per GPU sets it from its rank
  * PEAKSEG_HIP_MAX_BYTES         cap on the HBM one problem set may hold (suffix K/M/G/T); several
  *                               processes can then share one GPU (R's future workers)
- * PEAKSEG_HIP_PIECES_PER_FUNCTION  arena estimate, pieces per stored cost function (default 10;
- *                               the arena is doubled and the set rerun when it proves too small)
+ * PEAKSEG_HIP_PIECES_PER_FUNCTION  arena estimate, pieces per stored cost function (default 7;
+ *                               when it proves too small more memory is mapped behind the arena
+ *                               and the problems that ran out go on where they stopped)
  * PEAKSEG_HIP_SPILL_CAP / _SPILL_SLOTS  capacity (pieces per list, at most 32767) and initial
  *                               number of slots of the HBM spill pool for functions that outgrow LDS
  * PEAKSEG_HIP_CHECKPOINT=K / PEAKSEG_HIP_NO_CHECKPOINT=1  force / forbid the checkpointed store

@@ -519,11 +519,13 @@ int alloc_arena(psd_problem_set *s, unsigned long long pieces) {
 #ifndef PSD_EMU
   if (first && !s->arena_vmm) (void)arena_reserve(s);
   if (s->arena_vmm) {
-    /* Mappings are whole blocks, all of the size of the first allocation (a multiple of 2^19
-     * pieces: 2 MiB of the int array): measured on ROCm 7.2 / gfx950, hipMemSetAccess refuses
-     * ranges mapped in unequal sizes or at offsets finer than 2 MiB, although the reported
-     * granularity is 4 KiB (tools/vmm_probe.cpp). */
-    if (first) s->arena_block = (pieces + 0x7ffffull) & ~0x7ffffull;
+    /* Mappings are whole blocks of one size, an eighth of the first allocation (a multiple of
+     * 2^19 pieces: 2 MiB of the int array): measured on ROCm 7.2 / gfx950, hipMemSetAccess
+     * refuses ranges mapped in unequal sizes or at offsets finer than 2 MiB, although the
+     * reported granularity is 4 KiB (tools/vmm_probe.cpp).  Eight blocks, so that growth comes
+     * in steps of an eighth: memory that was used before costs 13-25 ms per GB to get
+     * (profiles/r03/probe_results.log), whether mapped or hipMalloc'ed. */
+    if (first) s->arena_block = ((pieces + 7ull) / 8ull + 0x7ffffull) & ~0x7ffffull;
     const unsigned long long blk = s->arena_block;
     pieces = (pieces + blk - 1) / blk * blk;
     if (pieces > s->arena_reserved) pieces = s->arena_reserved / blk * blk;
@@ -786,7 +788,7 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
    * (the 1e6 x 64 grid: 5.2 on average); an estimate that proves too small costs one more
    * launch, not a repeated solve (the arena grows in place, parked problems go on), so the
    * default no longer has to be generous: 10 instead of rounds 1-2's 16. */
-  double per_fn = 10.0;
+  double per_fn = 7.0;
   if (const char *e = getenv("PEAKSEG_HIP_PIECES_PER_FUNCTION")) {
     double v = atof(e);
     if (v >= 1.0) per_fn = v;
@@ -928,9 +930,9 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
 #endif
   /* arena: the reference's store holds 2 functions per data point with, on typical coverage
    * data, 2-14 pieces each.  Sized from that estimate
-   * (PEAKSEG_HIP_PIECES_PER_FUNCTION, default 16), never beyond nine tenths of what is free on
-   * the device or what PEAKSEG_HIP_MAX_BYTES allows; solve() doubles it and reruns if a problem
-   * reports PST_ARENA_FULL. */
+   * (PEAKSEG_HIP_PIECES_PER_FUNCTION, default 7: growth is cheap, memory is not), never beyond
+   * nine tenths of what is free on the device or what PEAKSEG_HIP_MAX_BYTES allows; solve()
+   * maps more and resumes the parked problems if one reports PST_ARENA_FULL. */
   s->arena_auto = arena_pieces == 0;
   unsigned long long want = arena_pieces;
   if (K > 0) {
@@ -1259,7 +1261,8 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
       } else {
         /* Full store: the arena GROWS in place.  How much more: what the unfinished problems' progress
          * says the rest of the set needs (pieces handed out so far x data points left / data
-         * points done, x 1.3), at least as much again as the arena has. */
+         * points done, x 1.3); at least a quarter of what the arena has where it grows by
+         * mapping, as much again where it grows by copying. */
         double done = 0.0, all = 0.0;
         for (int p = 0; p < s->n_problems; p++) {
           const double n = (double)s->contig_n[(size_t)s->prob_contig[(size_t)p]];
@@ -1267,7 +1270,7 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
           all += n;
           done += r.status == 0 ? n : (double)r.step_reached;
         }
-        unsigned long long more = s->arena_pieces;
+        unsigned long long more = s->arena_vmm ? s->arena_pieces / 4ull : s->arena_pieces;
         if (done > 0.0) {
           const double need = (double)s->arena_pieces * ((all - done) / done) * 1.3;
           if (need > (double)more) more = (unsigned long long)need;

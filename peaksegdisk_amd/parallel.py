@@ -105,7 +105,8 @@ def solve_grid(contigs, penalties, dist=None, device=0, lib=None, stats=None):
     gather.  Returns on rank 0 a dict (contig_index, penalty_index) -> dict(seg_start,
     seg_mean, summary) where summary = [n_segments, n_equality, max_intervals,
     total_intervals, best_cost]; None on other ranks.  stats (a dict, optional) receives this
-    rank's forward_ms (HIP events), kernel_build and hbm_bytes."""
+    rank's forward_ms (HIP events), kernel_build, hbm_bytes and the wall seconds of its phases
+    (create_s = upload + arena, solve_s, tables_s = download of the tables, close_s)."""
     from .grid import ProblemSet
     world = 1 if dist is None else dist.get_world_size()
     rank = 0 if dist is None else dist.get_rank()
@@ -118,10 +119,14 @@ def solve_grid(contigs, penalties, dist=None, device=0, lib=None, stats=None):
     local_of = {c: k for k, c in enumerate(used)}
     tables = []
     if mine:
+        import time
+        t0 = time.time()
         pset = ProblemSet([contigs[c] for c in used],
                           [(local_of[problems[i][0]], penalties[problems[i][1]]) for i in mine],
                           device=device or 0, lib=lib)
+        t1 = time.time()
         f_ms, _ = pset.solve()
+        t2 = time.time()
         if stats is not None:
             stats.update(forward_ms=f_ms, kernel_build=pset.kernel_build,
                          hbm_bytes=pset.hbm_bytes, problems=len(mine),
@@ -134,7 +139,11 @@ def solve_grid(contigs, penalties, dist=None, device=0, lib=None, stats=None):
                                 r.total_intervals, r.best_cost], dtype=np.float64)
             tables.append((np.concatenate([start, np.full(5, -2, np.int32)]),
                            np.concatenate([mean, summary])))
+        t3 = time.time()
         pset.close()
+        if stats is not None:  # where this rank's wall time went, seconds
+            stats.update(create_s=t1 - t0, solve_s=t2 - t1, tables_s=t3 - t2,
+                         close_s=time.time() - t3)
     gathered = gather_segment_tables(tables, dist, device)
     if rank != 0:
         return None
