@@ -48,6 +48,8 @@ extern "C" {
  * PEAKSEG_HIP_CKPT_OVERFLOW     initial size (pieces) of the pool that holds checkpoints of functions
  *                               too long for a checkpoint slot (adversarial data)
  * PEAKSEG_HIP_NO_PARK=1         rerun a set that ran out of arena instead of resuming its problems
+ * PEAKSEG_HIP_NO_VMM=1          arena from plain allocations (growth by allocate, copy, free) instead of
+ *                               HIP virtual-memory ranges that grow in place
  * PEAKSEG_HIP_VARIANT=lat|thr   force a build of the forward kernel
  * PEAKSEG_HIP_TIMING=1          phase timings of the file-level calls on stderr */
 
