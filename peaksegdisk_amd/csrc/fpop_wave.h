@@ -2200,17 +2200,16 @@ PSD_D void env_coop_classify(const L &f1, int n1, const L &f2, int n2, const S &
                             mth);
 }
 
-/* Which chunks of merged intervals the helper classifies: three of every five.  The chain wave
- * also compacts every chunk (and re-reads the pieces of the helper's chunks for that), so an
- * even split leaves the helper idle a third of the time. */
-PSD_D bool coop_helper_owns(int chunk) {
-  const int r = chunk % 5;
-  return r == 1 || r == 3 || r == 4;
-}
+/* Which chunks of merged intervals the helper classifies: all but every PSD_COOP_PERIOD-th.
+ * The chain wave also compacts every chunk (and re-reads the pieces of the helper's chunks for
+ * that); measured shares from 3/5 to all: profiles/r03/ab_hbm_helper_share_and_stealing.log. */
+#ifndef PSD_COOP_PERIOD
+#define PSD_COOP_PERIOD 4
+#endif
+PSD_D bool coop_helper_owns(int chunk) { return chunk % PSD_COOP_PERIOD != 0; }
 /* helper-owned chunks among chunks 0..chunk */
 PSD_D int coop_helper_chunks_upto(int chunk) {
-  const int r = chunk % 5;
-  return (chunk / 5) * 3 + (r >= 1 ? 1 : 0) + (r >= 3 ? 1 : 0) + (r >= 4 ? 1 : 0);
+  return (chunk / PSD_COOP_PERIOD) * (PSD_COOP_PERIOD - 1) + chunk % PSD_COOP_PERIOD;
 }
 /* the helper's share: its chunks, results to HBM, progress published chunk by chunk */
 template <class L, class S>
