@@ -182,11 +182,14 @@ def test_emu_fuzz_tiny_problems(psd, oracle_det, tmp_path):
     gp.test_fuzz_tiny_problems(psd, oracle_det, tmp_path, 150, 6)
 
 
-def test_emu_resident_search_exact_sequence(psd, oracle_det, known_answers, tmp_path):
+def test_emu_resident_search_exact_sequence(psd, oracle_det, known_answers, tmp_path, monkeypatch):
+    # host-side search logic: on the build without helper waves (half the fibers to emulate)
+    monkeypatch.setenv("PEAKSEG_HIP_VARIANT", "thr")
     gp2.test_resident_search_exact_sequence(psd, oracle_det, known_answers, tmp_path)
 
 
-def test_emu_search_batch_equals_single_searches(psd, tmp_path):
+def test_emu_search_batch_equals_single_searches(psd, tmp_path, monkeypatch):
+    monkeypatch.setenv("PEAKSEG_HIP_VARIANT", "thr")  # host-side logic, as above
     gp2.test_search_batch_equals_single_searches(psd, tmp_path, n_bins=400, with_mono=False)
 
 
@@ -225,7 +228,8 @@ def test_emu_worst_case_vignette_grid(psd, oracle_det, tmp_path):
     gp3.test_worst_case_vignette_grid(psd, oracle_det, tmp_path, sizes=(10, 100, 300))
 
 
-def test_emu_sequential_search_synthetic(psd, tmp_path):
+def test_emu_sequential_search_synthetic(psd, tmp_path, monkeypatch):
+    monkeypatch.setenv("PEAKSEG_HIP_VARIANT", "thr")  # host-side logic, as above
     gp3.test_sequential_search_on_a_long_contig(psd, tmp_path, n_bins=1500, peaks_int=2)
 
 
