@@ -253,15 +253,25 @@ def test_worst_case_vignette_grid(psd, oracle_det, tmp_path, sizes=(10, 100, 100
                 assert max(float(c[9]) for c in loss) > 128  # beyond LDS: the spill path
 
 
-def _oracle_search(problem_dir, peaks_int, cli=CLI_DET):
-    """sequentialSearch_dir (R/sequentialSearch_dir.R:31-99) driven by the oracle executable."""
+def _oracle_model(bg, pen_str, cli=CLI_DET):
+    run_cli(cli, bg, pen_str, "%s_penalty=%s.db" % (bg, pen_str))
+    c = read_loss("%s_penalty=%s_loss.tsv" % (bg, pen_str)).split("\t")
+    return {"penalty": pen_str, "peaks": int(c[2]), "total.loss": float(c[6])}
+
+
+def _oracle_search(problem_dir, peaks_int, cli=CLI_DET, known=None):
+    """sequentialSearch_dir (R/sequentialSearch_dir.R:31-99) driven by the oracle executable.
+    known: the oracle's models by penalty string, computed beforehand (all at once, in
+    parallel); the loop then only looks them up, and a penalty it asks for that is not among
+    them fails the test."""
     from peaksegdisk_amd.api import paste
     bg = os.path.join(problem_dir, "coverage.bedGraph")
 
     def model(pen_str):
-        run_cli(cli, bg, pen_str, "%s_penalty=%s.db" % (bg, pen_str))
-        c = read_loss("%s_penalty=%s_loss.tsv" % (bg, pen_str)).split("\t")
-        return {"penalty": pen_str, "peaks": int(c[2]), "total.loss": float(c[6])}
+        if known is not None:
+            assert pen_str in known, "the reference's loop asks for penalty %s" % pen_str
+            return known[pen_str]
+        return _oracle_model(bg, pen_str, cli)
     with ThreadPoolExecutor(max_workers=2) as pool:  # iteration 1: two independent models
         trace = list(pool.map(model, ["0", "Inf"]))
     over, under = trace[0], trace[1]
@@ -283,11 +293,13 @@ def _oracle_search(problem_dir, peaks_int, cli=CLI_DET):
 
 
 @GPU
-def test_sequential_search_on_a_long_contig(psd, tmp_path, n_bins=500000, peaks_int=250):
-    """BASELINE.json configs[2] at a twentieth of its length: sequentialSearch_dir on a 5e5-bin
+def test_sequential_search_on_a_long_contig(psd, tmp_path, n_bins=1000000, peaks_int=500):
+    """BASELINE.json configs[2] at a tenth of its length: sequentialSearch_dir on a 1e6-bin
     synthetic contig.  The resident driver must ask for the models the reference's loop asks
     for: same penalty strings in the same order, same peaks, and the chosen model's files
-    byte-identical to the oracle's (the oracle-driven loop runs in a thread meanwhile)."""
+    byte-identical to the oracle's.  The oracle solves every penalty the search visited (all
+    at once, one process each) and the reference's loop is then replayed on the oracle's
+    results: it must ask for exactly those penalties, in that order."""
     from peaksegdisk_amd import synthetic
     cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=1)
     gdir = tmp_path / "gpu" / "chrSynth-0-1"
@@ -300,22 +312,20 @@ def test_sequential_search_on_a_long_contig(psd, tmp_path, n_bins=500000, peaks_
             f.write("".join("chrSynth\t%d\t%d\t%d\n" % t for t in zip(
                 cs[o:o + 500000].tolist(), ce[o:o + 500000].tolist(), cnt[o:o + 500000].tolist())))
     os.link(bg, str(gdir / "coverage.bedGraph"))
-    box = {}
-    th = threading.Thread(target=lambda: box.update(trace=_oracle_search(str(odir), peaks_int)))
     t0 = time.time()
-    th.start()
     fit = psd.sequentialSearch_dir(str(gdir), peaks_int)
     gpu_s = time.time() - t0
-    th.join()
-    trace = box["trace"]
     got_pen = [psd.paste(float(p)) for p in fit.others["penalty"]]
+    with ThreadPoolExecutor(max_workers=len(os.sched_getaffinity(0))) as pool:
+        known = dict(zip(got_pen, pool.map(lambda pen: _oracle_model(bg, pen), got_pen)))
+    trace = _oracle_search(str(odir), peaks_int, known=known)
     assert got_pen == [m["penalty"] for m in trace]
     assert list(fit.others["peaks"]) == [m["peaks"] for m in trace]
     chosen = psd.paste(float(fit.loss["penalty"].iloc[0]))
     for suffix in ("_segments.bed", "_loss.tsv"):
         assert open("%s_penalty=%s%s" % (str(gdir / "coverage.bedGraph"), chosen, suffix),
                     "rb").read() == open("%s_penalty=%s%s" % (bg, chosen, suffix), "rb").read()
-    print("search of %d bins: %d models, %.1f s on the GPU path, %.1f s with the oracle loop"
+    print("search of %d bins: %d models, %.1f s on the GPU path, %.1f s with the oracle's models"
           % (n_bins, len(trace), gpu_s, time.time() - t0))
 
 
