@@ -787,11 +787,15 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
   /* pieces per stored function the arena is first sized for.  Typical coverage data needs 2-14
    * (the 1e6 x 64 grid: 5.2 on average); an estimate that proves too small costs one more
    * launch, not a repeated solve (the arena grows in place, parked problems go on), so the
-   * default no longer has to be generous: 10 instead of rounds 1-2's 16. */
+   * default no longer has to be generous: 7 instead of rounds 1-2's 16. */
   double per_fn = 7.0;
+  bool per_fn_given = false;
   if (const char *e = getenv("PEAKSEG_HIP_PIECES_PER_FUNCTION")) {
     double v = atof(e);
-    if (v >= 1.0) per_fn = v;
+    if (v >= 1.0) {
+      per_fn = v;
+      per_fn_given = true;
+    }
   }
   s->max_bytes = env_bytes("PEAKSEG_HIP_MAX_BYTES");
   int K = 0;
@@ -937,7 +941,13 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
   unsigned long long want = arena_pieces;
   if (K > 0) {
     /* one region per chain and problem: the records of K + 1 data points */
-    s->ckpt_pieces_per_fn = (unsigned long long)(per_fn * 2.0);
+    /* The checkpointed store cannot park: a block whose records outgrow the region during the
+     * decoding's recomputation costs the problem a second solve from its first data point
+     * (measured with 14 per function: 42 of the 1536 problems of the scaled config 4, all at
+     * large penalties, the set's time doubled).  So this estimate stays generous -- 32 per
+     * function, the longest functions of the 1e6-1e7 grids have 25-27 -- and costs little:
+     * regions are (K + 1) functions per chain, not the whole contig. */
+    s->ckpt_pieces_per_fn = per_fn_given ? (unsigned long long)(per_fn * 2.0) : 32ull;
     if (s->ckpt_pieces_per_fn < 8) s->ckpt_pieces_per_fn = 8;
     d.ckpt_region = (unsigned long long)(K + 1) * s->ckpt_pieces_per_fn;
     want = d.ckpt_region * 2ull * (unsigned long long)n_problems;
