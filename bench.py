@@ -335,6 +335,9 @@ def main():
                  # 0: every cost function stored; K: the checkpointed store (picked when the
                  # full store of rank 0's share would not fit its HBM)
                  "checkpoint_interval": stats.get("checkpoint_interval"),
+                 # kernel launches of rank 0's solve: 1 unless problems ran out of room and
+                 # were resumed (full store) or solved again (checkpointed store)
+                 "launches": stats.get("launches"),
                  "rank0_phase_seconds": {k: round(stats[k], 3) for k in
                                          ("create_s", "solve_s", "tables_s", "close_s")
                                          if k in stats}}

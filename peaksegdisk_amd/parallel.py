@@ -130,7 +130,8 @@ def solve_grid(contigs, penalties, dist=None, device=0, lib=None, stats=None):
         if stats is not None:
             stats.update(forward_ms=f_ms, kernel_build=pset.kernel_build,
                          hbm_bytes=pset.hbm_bytes, problems=len(mine),
-                         checkpoint_interval=pset.checkpoint_interval)
+                         checkpoint_interval=pset.checkpoint_interval,
+                         launches=pset.solve_stats[0])
         for k in range(len(mine)):
             r = pset.result(k)
             start, mean = pset.segments(k)

@@ -588,6 +588,9 @@ def test_checkpointed_store_equals_full_store(psd, oracle_det, tmp_path, monkeyp
             ck = ProblemSet([(cnt, w)], problems)
             ck.solve()
             assert ck.checkpoint_interval == K and ck.kernel_build == build
+            # the regions' default size must hold every block: a relaunch here means solving a
+            # problem twice (round 3: regions of 14 pieces per function doubled config 4's time)
+            assert ck.solve_stats[0] == 1, (K, build, ck.solve_stats)
             for i in range(len(pens)):
                 r = ck.result(i)
                 assert r.status == 0, (K, build, pens[i], r.kernel_status)
