@@ -246,3 +246,7 @@ def test_emu_batch_with_duplicate_problems(psd, oracle_det, tmp_path):
 def test_emu_arena_regrowth_resumes(psd, oracle_det, tmp_path, monkeypatch):
     gp3.test_arena_regrowth_resumes_instead_of_repeating(psd, oracle_det, tmp_path, monkeypatch,
                                                          n_bins=1000)
+
+
+def test_emu_checkpointed_store_large_penalties(psd, monkeypatch):
+    gp3.test_checkpointed_store_large_penalties_single_launch(psd, monkeypatch, n_bins=1500)

@@ -329,6 +329,42 @@ def test_sequential_search_on_a_long_contig(psd, tmp_path, n_bins=1000000, peaks
           % (n_bins, len(trace), gpu_s, time.time() - t0))
 
 
+@GPU
+def test_checkpointed_store_large_penalties_single_launch(psd, monkeypatch, n_bins=1000000):
+    """The checkpointed store cannot park a problem: a block whose records outgrow its region
+    during the decoding's recomputation costs a second solve from the first data point.  Large
+    penalties on a long contig are where functions are longest (8-9 pieces on average, 25 at
+    most): with the default region size they must go through in ONE launch and equal the full
+    store bit for bit.  (Round 3 lowered the arena estimate to 7 pieces per function, the
+    regions followed to 14, and config 4 at 0.4 of its size took 149 s instead of 77 s.)"""
+    from peaksegdisk_amd import ProblemSet, synthetic
+    cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=5)
+    w = (ce - cs).astype(np.int32)
+    # (at this length and these two penalties regions of 14 per function are outgrown)
+    problems = [(0, float(p)) for p in ("13894.9549437314", "100000")]
+    monkeypatch.delenv("PEAKSEG_HIP_PIECES_PER_FUNCTION", raising=False)
+    monkeypatch.setenv("PEAKSEG_HIP_NO_CHECKPOINT", "1")
+    full = ProblemSet([(cnt, w)], problems)
+    full.solve()
+    want = [(full.result(i).n_segments, full.result(i).total_intervals, full.result(i).best_cost)
+            + tuple(a.copy() for a in full.segments(i)) for i in range(len(problems))]
+    full.close()
+    monkeypatch.delenv("PEAKSEG_HIP_NO_CHECKPOINT")
+    monkeypatch.setenv("PEAKSEG_HIP_CHECKPOINT", "2048")
+    ck = ProblemSet([(cnt, w)], problems)
+    ck.solve()
+    assert ck.checkpoint_interval == 2048
+    assert ck.solve_stats[0] == 1, "a region was outgrown: %r" % (ck.solve_stats,)
+    for i in range(len(problems)):
+        r = ck.result(i)
+        assert r.status == 0
+        s1, m1 = ck.segments(i)
+        assert (r.n_segments, r.total_intervals, r.best_cost) == want[i][:3]
+        assert np.array_equal(s1, want[i][3])
+        assert np.array_equal(m1.view(np.uint64), want[i][4].view(np.uint64))
+    ck.close()
+
+
 _FSIZE_CHILD = r"""
 import ctypes, os, resource, signal, sys
 sys.path.insert(0, %(root)r)
