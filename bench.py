@@ -242,7 +242,7 @@ def main():
         import ctypes
         _native.lib = _native.declare(ctypes.CDLL(os.environ["PSD_BENCH_TEST_LIB"]))
     from peaksegdisk_amd import ProblemSet, synthetic
-    from peaksegdisk_amd.parallel import gather_segment_tables, solve_grid
+    from peaksegdisk_amd.parallel import gather_problem_set, solve_grid
 
     pen_str = synthetic.penalty_grid(args.penalties)
     penalties = [float(p) for p in pen_str]
@@ -265,8 +265,9 @@ def main():
 
         def one_step():
             f_ms, _ = pset.solve()
-            tables = [pset.segments(p) for p in range(len(problems))]
-            gathered = gather_segment_tables(tables, dist, device)
+            # every segment table leaves the device inside the timed region: packed in HBM,
+            # then one download (N = 1) or the RCCL gather to rank 0 (N > 1)
+            gathered = gather_problem_set(pset, dist, device)
             return f_ms, gathered
 
         units_per_step = args.bins * args.penalties * world
@@ -316,6 +317,15 @@ def main():
         extra = {"hbm_bytes_resident": pset.hbm_bytes, "arena_bytes_used": pset.arena_bytes_used,
                  "kernel_build": pset.kernel_build,
                  "serial_env_replays": int(sum(r.n_serial_env for r in results))}
+        if rank == 0:
+            # what the last step's gather left on rank 0: every rank's tables, exact sizes
+            assert len(gathered) == world
+            extra["tables_on_rank0"] = int(sum(len(t) for t, _ in gathered))
+            assert extra["tables_on_rank0"] == world * len(problems)
+            for p, (gs, gm) in enumerate(gathered[0][0]):
+                start, mean = pset.segments(p)
+                assert np.array_equal(gs, start) and np.array_equal(gm.view(np.uint64),
+                                                                   mean.view(np.uint64))
     elif rank == 0:
         assert len(gathered) == len(lengths) * len(penalties)
         total_pieces = 0.0

@@ -147,7 +147,12 @@ typedef struct {
 int peakseg_hip_device_count(void);
 /* shader clock of a device in kHz, 0 when unknown */
 int peakseg_hip_device_clock_khz(int device);
+/* text of the calling thread's last FAILURE (statuses >= 12 carry their detail here) */
 const char *peakseg_hip_last_error(void);
+/* Something worth knowing about the calling thread's last problem-set solve although it
+ * succeeded (e.g. the mixed launch's wait for its latency-build workgroups ran into its bound);
+ * "" when there is nothing.  Never part of an error message. */
+const char *peakseg_hip_last_warning(void);
 
 /* Upload contigs (count = 4th bedGraph column, weight = chromEnd-chromStart) and the
  * problem list to HBM and allocate the arena (arena_pieces = 0: sized automatically and
@@ -204,6 +209,41 @@ unsigned long long peakseg_hip_problem_set_arena_bytes_used(psd_problem_set *set
  * was repeated). */
 int peakseg_hip_problem_set_solve_stats(psd_problem_set *set, int *launches,
                                         unsigned long long *steps_run);
+
+/* The arena of the set (include/../csrc/fpop_types.h): pieces per block, blocks mapped now, and
+ * how many of them the last solve mapped WHILE its kernels ran (0 with
+ * PEAKSEG_HIP_NO_LIVE_GROWTH=1, with an explicit arena size and for the checkpointed store). */
+int peakseg_hip_problem_set_arena_stats(psd_problem_set *set, unsigned long long *block_pieces,
+                                        int *blocks, int *blocks_added_live);
+
+/* How often the last solve parked a problem (the arena had run out; the problem was resumed
+ * after more had been mapped) and how many pieces of the overflow pool -- where a parked
+ * problem keeps functions too long for its park slot -- those parks took. */
+int peakseg_hip_problem_set_park_stats(psd_problem_set *set, int *parks,
+                                       unsigned long long *overflow_pool_pieces);
+
+/* Pack the segment tables of a solved set at their exact sizes, IN HBM: problem p's rows
+ * (rows_out[p] of them, n_problems entries, host) follow problem p-1's.  Returns the total
+ * number of rows, -1 on failure.  *start_dev / *mean_dev receive the device addresses of the
+ * packed arrays (valid until the set is solved again or destroyed): what the multi-GPU gather
+ * hands to RCCL without a host round trip (peaksegdisk_amd/parallel.py);
+ * peakseg_hip_problem_set_packed_download copies them to host arrays of that many rows. */
+long long peakseg_hip_problem_set_pack_tables(psd_problem_set *set, long long *rows_out,
+                                              const int **start_dev, const double **mean_dev);
+int peakseg_hip_problem_set_packed_download(psd_problem_set *set, int *start_out, double *mean_out);
+
+/* Shader cycles a problem's workgroup ran in the last launch that worked on it (0 when
+ * unknown); with the device's clock, data points / cycles is the problem's rate: the dealing of
+ * problems to ranks is sized from it. */
+long long peakseg_hip_problem_set_cycles(psd_problem_set *set, int problem);
+/* Data points per second one problem advanced at in this process's last clean solves on the
+ * latency build (a CU per problem) and on the throughput build (a full chip). */
+void peakseg_hip_measured_rates(double *lat_rate, double *thr_rate);
+
+/* Tests: the bound on the number of polls of a wait between the waves of a workgroup, and (in
+ * builds with -DPSD_SPIN_STATS, 0 otherwise) the largest poll count a problem's waves saw. */
+long long peakseg_hip_spin_limit(void);
+int peakseg_hip_problem_set_max_spin(psd_problem_set *set, int problem);
 
 /* Change one problem's penalty in place (the contig stays resident, the arena is reused by the
  * next solve): what the penalty search does between its dynamic programs.  0 or -1. */

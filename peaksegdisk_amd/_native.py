@@ -123,6 +123,27 @@ def declare(lib):
     lib.peakseg_hip_problem_set_solve_stats.restype = c.c_int
     lib.peakseg_hip_device_clock_khz.argtypes = [c.c_int]
     lib.peakseg_hip_device_clock_khz.restype = c.c_int
+    lib.peakseg_hip_problem_set_park_stats.argtypes = [
+        c.c_void_p, c.POINTER(c.c_int), c.POINTER(c.c_ulonglong)]
+    lib.peakseg_hip_problem_set_park_stats.restype = c.c_int
+    lib.peakseg_hip_problem_set_pack_tables.argtypes = [
+        c.c_void_p, c.c_void_p, c.POINTER(c.c_void_p), c.POINTER(c.c_void_p)]
+    lib.peakseg_hip_problem_set_pack_tables.restype = c.c_longlong
+    lib.peakseg_hip_problem_set_packed_download.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p]
+    lib.peakseg_hip_problem_set_packed_download.restype = c.c_int
+    lib.peakseg_hip_problem_set_cycles.argtypes = [c.c_void_p, c.c_int]
+    lib.peakseg_hip_problem_set_cycles.restype = c.c_longlong
+    lib.peakseg_hip_measured_rates.argtypes = [c.POINTER(c.c_double), c.POINTER(c.c_double)]
+    lib.peakseg_hip_measured_rates.restype = None
+    lib.peakseg_hip_spin_limit.argtypes = []
+    lib.peakseg_hip_spin_limit.restype = c.c_longlong
+    lib.peakseg_hip_problem_set_max_spin.argtypes = [c.c_void_p, c.c_int]
+    lib.peakseg_hip_problem_set_max_spin.restype = c.c_int
+    lib.peakseg_hip_last_warning.argtypes = []
+    lib.peakseg_hip_last_warning.restype = c.c_char_p
+    lib.peakseg_hip_problem_set_arena_stats.argtypes = [
+        c.c_void_p, c.POINTER(c.c_ulonglong), c.POINTER(c.c_int), c.POINTER(c.c_int)]
+    lib.peakseg_hip_problem_set_arena_stats.restype = c.c_int
     return lib
 
 
@@ -139,6 +160,10 @@ EXPORTED_SYMBOLS = [
     "peakseg_hip_problem_set_set_penalty", "peakseg_hip_problem_set_arena_bytes_used",
     "peakseg_hip_paste_double", "peakseg_hip_problem_set_checkpoint_interval",
     "peakseg_hip_problem_set_solve_stats", "peakseg_hip_device_clock_khz",
+    "peakseg_hip_last_warning", "peakseg_hip_problem_set_arena_stats",
+    "peakseg_hip_problem_set_park_stats", "peakseg_hip_problem_set_pack_tables",
+    "peakseg_hip_problem_set_packed_download", "peakseg_hip_problem_set_cycles",
+    "peakseg_hip_measured_rates", "peakseg_hip_spin_limit", "peakseg_hip_problem_set_max_spin",
 ]
 
 if not os.path.exists(LIB_PATH):

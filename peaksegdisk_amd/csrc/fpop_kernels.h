@@ -69,28 +69,110 @@ PSD_D void copy_list_wave(const L &src, int n, const L &dst) {
   }
 }
 
+/* where piece offset `off` of the arena lives (a.ar_block[] must hold the block already) */
+struct ArenaPtr {
+  gdouble *mx, *prv;
+  gint *di;
+};
+PSD_D ArenaPtr arena_ptr(char *block_base, int block_log2, unsigned long long within) {
+  ArenaPtr r;
+  r.mx = (gdouble *)block_base + within;
+  r.prv = (gdouble *)(block_base + (8ull << block_log2)) + within;
+  r.di = (gint *)(block_base + (16ull << block_log2)) + within;
+  return r;
+}
+PSD_D ArenaPtr arena_at(const DeviceArgs &a, unsigned long long off) {
+  const int blg = a.ar_block_log2;
+  /* (every lane loads the same entry: the address is wave-uniform, say so) */
+  return arena_ptr(uniform_p(agent_load_ptr(&a.ar_block[off >> blg])), blg,
+                   off & ((1ull << blg) - 1ull));
+}
+
 struct ArenaCursor {
   unsigned long long base; /* first piece of the current chunk run */
+  gdouble *mx, *prv;       /* ... and where it lives */
+  gint *di;
   int used, room;
   int store; /* 0: the forward pass of the checkpointed store keeps no per-step records */
 };
+PSD_D void cursor_clear(ArenaCursor &cur, int store) {
+  cur.base = 0;
+  cur.mx = cur.prv = nullptr;
+  cur.di = nullptr;
+  cur.used = 0;
+  cur.room = 0;
+  cur.store = store;
+}
+PSD_D void cursor_point(const DeviceArgs &a, ArenaCursor &cur, unsigned long long base, int room) {
+  const ArenaPtr q = arena_at(a, base);
+  cur.base = base;
+  cur.mx = q.mx;
+  cur.prv = q.prv;
+  cur.di = q.di;
+  cur.used = 0;
+  cur.room = room;
+}
 
 /* Reserve arena room for a function of n pieces: the next run of whole chunks for this wave
- * (cold: once per chunk of 2^ar_chunk_log2 pieces).  Returns the first piece index of the run;
- * ~0 when the arena is exhausted. */
+ * (cold: once per chunk of 2^ar_chunk_log2 pieces), inside ONE block.  Returns the first piece
+ * index of the run; ~0 when the arena is exhausted.  A run beyond what was mapped at launch
+ * waits for the host, which maps ahead of ar_used while the kernel runs; the arena is exhausted
+ * when the host says that no more will come (or never answers). */
 PSD_COLD_DEV unsigned long long arena_take(const DeviceArgs &a, int n) {
   if (a.ckpt_interval > 0) return ~0ull; /* checkpointed store: the wave's region is all it has */
-  const int lg = a.ar_chunk_log2;
+  const int lg = a.ar_chunk_log2, blg = a.ar_block_log2;
   const unsigned long long chunks = ((unsigned long long)uniform_i(n) + (1ull << lg) - 1ull) >> lg;
-  unsigned long long first = 0;
-  if (lane_id() == 0) first = atomicAdd(a.ar_next_chunk, chunks);
-  first = psd_d2u(rdlane_d(psd_u2d(first), 0));
-  if (((first + chunks) << lg) > a.ar_cap) return ~0ull;
-  return first << lg;
+  if ((chunks << lg) > (1ull << blg)) return ~0ull; /* (a function is never longer than a block) */
+  /* How long a wave waits for the host to map a block: a block is 10-340 MB at 13-35 ms per GB,
+   * so a fifth of a second is generous -- and it must stay far below the bound on the waits
+   * BETWEEN waves (WAIT_SPIN_LIMIT, seconds): the other chain's wave sits at the data point's
+   * barrier meanwhile.  Past it the problem is parked, which costs a relaunch, not a result. */
+  constexpr long long LIVE_WAIT_CYCLES = 480000000ll; /* 0.2 s at 2.4 GHz */
+  constexpr int LIVE_SPIN_LIMIT = 1 << 22; /* (the emulator has no clock: polls) */
+  for (;;) {
+    unsigned long long first = 0;
+    if (lane_id() == 0) {
+      first = atomicAdd(a.ar_next_chunk, chunks);
+      if (a.ar_used) sys_add_u64(a.ar_used, chunks << lg);
+    }
+    first = psd_d2u(rdlane_d(psd_u2d(first), 0));
+    const unsigned long long lo = first << lg, hi = (first + chunks) << lg;
+    if ((lo >> blg) != ((hi - 1ull) >> blg)) continue; /* straddles two blocks: the next run */
+    if (hi > a.ar_cap) {
+      if (a.ar_live == nullptr) return ~0ull;
+      bool mapped = false;
+      const long long t_wait = cycle_now();
+      for (int spin = 0; spin < LIVE_SPIN_LIMIT; spin++) {
+        /* (the flag first: a capacity published before it is final) */
+        const unsigned long long final_now = psd_d2u(uniform_d(psd_u2d(sys_load_u64(&a.ar_live[1]))));
+        const unsigned long long cap_now = psd_d2u(uniform_d(psd_u2d(sys_load_u64(&a.ar_live[0]))));
+        if (hi <= cap_now) {
+          mapped = true;
+          break;
+        }
+        if (final_now || cycle_now() - t_wait > LIVE_WAIT_CYCLES) break;
+        spin_pause();
+      }
+      if (!mapped) return ~0ull;
+      /* a block the host added during this launch: its address goes into the device table */
+      const unsigned long long blk = lo >> blg;
+      if (lane_id() == 0)
+        agent_store_ptr(&a.ar_block[blk], (char *)sys_load_u64(&a.ar_live[2ull + blk]));
+      wave_sync();
+    }
+    return lo;
+  }
 }
 PSD_D int arena_room_for(const DeviceArgs &a, int n) {
   const int lg = a.ar_chunk_log2;
   return (int)((((unsigned)n + (1u << lg) - 1u) >> lg) << lg);
+}
+/* the next run of chunks for a function of n pieces -> cursor; false when the arena is full */
+PSD_D bool cursor_take(const DeviceArgs &a, ArenaCursor &cur, int n) {
+  unsigned long long base = psd_d2u(uniform_d(psd_u2d(arena_take(*a.self, n))));
+  if (base == ~0ull) return false;
+  cursor_point(a, cur, base, arena_room_for(a, n));
+  return true;
 }
 
 /* Append one function's backtrack record to the arena; returns false when it is full. */
@@ -99,23 +181,19 @@ PSD_D bool arena_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &f, i
                             unsigned long long fn_index) {
   const int lane = lane_id();
   if (!cur.store) return true;
-  if (n > cur.room - cur.used) {
-    unsigned long long base = psd_d2u(uniform_d(psd_u2d(arena_take(*a.self, n))));
-    if (base == ~0ull) return false;
-    cur.base = base;
-    cur.used = 0;
-    cur.room = arena_room_for(a, n);
-  }
-  unsigned long long off = cur.base + (unsigned long long)cur.used;
+  if (n > cur.room - cur.used && !cursor_take(a, cur, n)) return false;
+  const int at = cur.used;
   for (int base = 0; base < n; base += WAVE) {
     int i = base + lane;
     if (i < n) {
-      ((gdouble *)a.ar_mx)[off + i] = f.mx(i);
-      ((gdouble *)a.ar_prv)[off + i] = f.prv(i);
-      ((gint *)a.ar_di)[off + i] = f.di(i);
+      cur.mx[at + i] = f.mx(i);
+      cur.prv[at + i] = f.prv(i);
+      cur.di[at + i] = f.di(i);
     }
   }
-  if (lane == 0) ((gull *)a.fn_ref)[fn_index] = (off << FN_COUNT_BITS) | (unsigned long long)n;
+  if (lane == 0)
+    ((gull *)a.fn_ref)[fn_index] =
+        ((cur.base + (unsigned long long)at) << FN_COUNT_BITS) | (unsigned long long)n;
   cur.used += n;
   return true;
 }
@@ -131,18 +209,11 @@ PSD_D bool scale_add_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &
   const int lane = lane_id();
   bool ok = true;
   store = store && cur.store != 0;
-  if (store && n > cur.room - cur.used) {
-    unsigned long long base = psd_d2u(uniform_d(psd_u2d(arena_take(*a.self, n))));
-    if (base == ~0ull) {
-      ok = false;
-      store = false;
-    } else {
-      cur.base = base;
-      cur.used = 0;
-      cur.room = arena_room_for(a, n);
-    }
+  if (store && n > cur.room - cur.used && !cursor_take(a, cur, n)) {
+    ok = false;
+    store = false;
   }
-  const unsigned long long off = cur.base + (unsigned long long)cur.used;
+  const int at = cur.used;
   for (int base = 0; base < n; base += WAVE) {
     int i = base + lane;
     if (i < n) {
@@ -158,14 +229,16 @@ PSD_D bool scale_add_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &
       f.Log(i) = lo * inv_cum_weight;
       f.Con(i) = co * inv_cum_weight;
       if (store) {
-        ((gdouble *)a.ar_mx)[off + i] = mx; /* (in a called function `a` is in memory) */
-        ((gdouble *)a.ar_prv)[off + i] = prv;
-        ((gint *)a.ar_di)[off + i] = di;
+        cur.mx[at + i] = mx;
+        cur.prv[at + i] = prv;
+        cur.di[at + i] = di;
       }
     }
   }
   if (store) {
-    if (lane == 0) ((gull *)a.fn_ref)[fn_index] = (off << FN_COUNT_BITS) | (unsigned long long)n;
+    if (lane == 0)
+      ((gull *)a.fn_ref)[fn_index] =
+          ((cur.base + (unsigned long long)at) << FN_COUNT_BITS) | (unsigned long long)n;
     cur.used += n;
   }
   return ok;
@@ -552,16 +625,17 @@ PSD_D void backtrack_wave(const DeviceArgs &a, int p, int N, BtState &bt, unsign
     /* findMean (fpl:643-653) on the restored function (drv:44-54): piece k spans
      * [max_{k-1}, max_k], the first from -Inf; the first match wins. */
     bool found = false;
+    const ArenaPtr rec = arena_at(a, off); /* (a record never straddles a block) */
     for (int base = 0; base < n; base += WAVE) {
       int k = base + lane;
       bool hit = false;
       int di = 0;
       double prv = 0.0;
       if (k < n) {
-        double mxk = a.ar_mx[off + k];
-        double mnk = k == 0 ? -PSD_INF : a.ar_mx[off + k - 1];
-        di = a.ar_di[off + k];
-        prv = a.ar_prv[off + k];
+        double mxk = rec.mx[k];
+        double mnk = k == 0 ? -PSD_INF : rec.mx[k - 1];
+        di = rec.di[k];
+        prv = rec.prv[k];
         hit = mnk <= best_log_mean && best_log_mean <= mxk;
       }
       unsigned long long m = ballot(hit);
@@ -622,12 +696,15 @@ PSD_COLD_DEV void block_sync_cold(int chain) { block_sync(uniform_i(chain)); }
  * aborts the problem).  Otherwise the workgroup barrier. */
 PSD_D bool step_sync(int chain, unsigned seq) {
 #ifdef PSD_FLAG_BARRIER
-  constexpr int SPIN_LIMIT = 1 << 26; /* seconds */
+  constexpr int SPIN_LIMIT = WAIT_SPIN_LIMIT; /* seconds */
   wave_sync();
   if (lane_id() == 0) flag_store((int *)&g_sm.arrived[chain], (int)seq);
   for (int spin = 0; spin < SPIN_LIMIT; spin++) {
     /* lane 0's reading decides for the wave */
-    if (rdlane_i(flag_load((int *)&g_sm.arrived[1 - chain]), 0) - (int)seq >= 0) return true;
+    if (rdlane_i(flag_load((int *)&g_sm.arrived[1 - chain]), 0) - (int)seq >= 0) {
+      PSD_SPIN_NOTE(spin);
+      return true;
+    }
     spin_pause();
   }
   return false;
@@ -655,8 +732,8 @@ PSD_COLD_DEV int take_spill_slot(const DeviceArgs &a, int chain) {
  * Checkpoint slot k of a problem holds the two live functions after data point (k+1) K: per
  * slot 6 + 12 cap doubles {cum_weight, -, overflow offsets of the two chains, interval totals
  * of the two chains (bit patterns), then per chain Lin, Log, Con, mn, mx, prv} and 8 + 2 cap
- * ints {n_up, n_down, data point, max intervals of the two chains, spill steps, -, -, then per
- * chain data_i}.  The full store keeps ONE such slot per problem: the park slot, written when
+ * ints {n_up, n_down, data point, max intervals of the two chains, spill steps, sequential
+ * envelope replays of the two chains, then per chain data_i}.  The full store keeps ONE such slot per problem: the park slot, written when
  * the arena runs out (park_state) and read back when the problem is resumed.  A function with more than cap pieces lives in the overflow pool (6 n doubles from
  * 6 off, n ints from off) and the slot only holds its offset. */
 constexpr int CKPT_HDR_F64 = 6, CKPT_HDR_I32 = 8;
@@ -777,6 +854,7 @@ PSD_COLD_DEV void park_counters_save(const DeviceArgs &a, int p, int chain, int 
   if (lane_id() == 0) {
     a.ckpt_f64[ckpt_f64_at(a, slot) + 4 + (size_t)chain] = psd_u2d(total_intervals);
     a.ckpt_i32[ckpt_i32_at(a, slot) + 3 + (size_t)chain] = max_intervals;
+    a.ckpt_i32[ckpt_i32_at(a, slot) + 6 + (size_t)chain] = g_sm.serial[chain];
     if (chain == 1) {
       a.ckpt_i32[ckpt_i32_at(a, slot) + 2] = t;
       a.ckpt_i32[ckpt_i32_at(a, slot) + 5] = spill_steps;
@@ -825,7 +903,12 @@ PSD_D void forward_body(const DeviceArgs &a) {
     g_sm.abort_err[0] = g_sm.abort_err[1] = g_sm.abort_err[2] = 0;
     for (int i = 0; i < 6; i++) g_sm.n[i] = 0;
     g_sm.serial[0] = g_sm.serial[1] = 0;
+    g_sm.total_up = 0; /* (read by the down wave's result even when the pass stops early) */
+    g_sm.max_up = 0;
     g_sm.arrived[0] = g_sm.arrived[1] = 0xffffffffu;
+#ifdef PSD_SPIN_STATS
+    g_sm.spin_max[0] = g_sm.spin_max[1] = g_sm.spin_max[2] = g_sm.spin_max[3] = 0;
+#endif
 #ifdef PSD_PROFILE
     for (int i = 0; i < N_PROF; i++)
       g_sm.prof[0][i] = g_sm.prof[1][i] = g_sm.prof[2][i] = g_sm.prof[3][i] = 0;
@@ -857,10 +940,7 @@ PSD_D void forward_body(const DeviceArgs &a) {
   const unsigned long long fn_down = fn_up + fn_stride;
   const unsigned long long fn_mine = chain == 1 ? fn_down : fn_up;
   ArenaCursor cur;
-  cur.base = 0;
-  cur.used = 0;
-  cur.room = 0;
-  cur.store = K > 0 ? 0 : 1;
+  cursor_clear(cur, K > 0 ? 0 : 1);
   unsigned long long total_intervals = 0;
   int max_intervals = 0;
   int spill_steps = 0;
@@ -889,9 +969,7 @@ PSD_D void forward_body(const DeviceArgs &a) {
   r.prev_log_mean = 0.0;
   r.prev_seg_end = -1;
   unsigned sync_no = 0; /* parity slot of the abort flags: one per barrier */
-#ifdef PSD_PROFILE
-  long long t_begin = cycle_now();
-#endif
+  const long long t_begin = cycle_now();
   bool resumed_abort = false;
   if (!CKPT && a.prob_resume != nullptr) {
     /* A problem parked by an earlier launch (the arena had run out): its two functions, the
@@ -918,6 +996,10 @@ PSD_D void forward_body(const DeviceArgs &a) {
         total_intervals = park_total_intervals(*a.self, p, chain);
         max_intervals = park_int(*a.self, p, 3 + chain);
         spill_steps = park_int(*a.self, p, 5);
+        {
+          const int n_serial = park_int(*a.self, p, 6 + chain);
+          if (lane == 0) g_sm.serial[chain] = n_serial;
+        }
         t_first = t_resume; /* (t_lo stays 0: the decoding goes back to the first data point) */
         block_sync(chain); /* both functions are in place before either chain reads the other's */
       }
@@ -1132,10 +1214,14 @@ PSD_D void forward_body(const DeviceArgs &a) {
   t_lo = c == 0 ? 0 : c * K + 1;
   t_hi = (c + 1) * K + 1 < N ? (c + 1) * K + 1 : N;
   t_first = t_lo;
-  cur.base = ((unsigned long long)p * 2ull + (unsigned long long)chain) * a.ckpt_region;
-  cur.used = 0;
-  cur.room = (int)a.ckpt_region;
-  cur.store = 1;
+  {
+    /* this wave's region: regions are packed whole into the arena's blocks */
+    const unsigned long long per_block = (1ull << a.ar_block_log2) / a.ckpt_region;
+    const unsigned long long region = (unsigned long long)p * 2ull + (unsigned long long)chain;
+    cursor_point(a, cur, ((region / per_block) << a.ar_block_log2) + (region % per_block) * a.ckpt_region,
+                 (int)a.ckpt_region);
+    cur.store = 1;
+  }
   in_hbm = false;
   b = 0;
   if (c == 0) {
@@ -1185,6 +1271,11 @@ PSD_D void forward_body(const DeviceArgs &a) {
     r.step_reached = step_reached;
     r.spill_steps = spill_steps;
     r.parked = parked;
+    r.max_spin = 0;
+#ifdef PSD_SPIN_STATS
+    for (int w = 0; w < 4; w++) r.max_spin = g_sm.spin_max[w] > r.max_spin ? g_sm.spin_max[w] : r.max_spin;
+#endif
+    r.cycles = cycle_now() - t_begin;
     if (lane == 0) a.result[p] = r;
   }
 }

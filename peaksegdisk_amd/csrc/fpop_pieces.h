@@ -215,47 +215,68 @@ PSD_D bool has_two_roots(const Coef &c, const PieceOpt &o, double equals) {
 /* The reference's Newton loops (fpl:98-124,158-188) also track the closest iterate on each
  * side of the root, but only use that bracket when 100 steps were not enough.  The hot loops
  * below iterate without the bookkeeping (about a fifth of the loop's instructions); if step
- * 100 is ever reached they hand over to *_root_full, which repeats the solve from the start
- * with the bracket -- same iterates, same result. */
+ * 100 is ever reached they hand over to newton_with_bracket, which repeats the solve from the
+ * start with the bracket -- same iterates, same result. */
 
-/* fpl:69-127 in full: Newton in mean space from argmin_mean+1, with the bracket fallback. */
-PSD_COLD_DEV double larger_root_full(Coef c, double optimal_mean, double optimal_cost,
-                                     double equals) {
-  double candidate_root = optimal_mean + 1;
-  double candidate_cost, deriv;
-  double closest_positive_cost = PSD_INF, closest_positive_mean = PSD_INF;
-  double closest_negative_cost = -PSD_INF, closest_negative_mean = PSD_INF;
-  if (optimal_cost < 0) {
-    closest_negative_cost = optimal_cost;
-    closest_negative_mean = optimal_mean;
+/* A solve that ran into the step cap (or met a rare exp/log argument), redone from its start
+ * with what the reference keeps for exactly this case (fpl:84-124,145-188): of all iterates,
+ * the one whose residual is closest to zero from above and the one closest from below.  At the
+ * cap the answer is the better of the last iterate and the midpoint of that bracket.
+ * IN_LOG_SPACE: the iterates are log-means (the smaller root; residual by getCost, slope
+ * Linear e^x + Log), otherwise means (the larger root; residual by PoissonLoss, slope
+ * Linear + Log / m, answer returned as a log-mean).  The same iterates as the hot loops below:
+ * same operations, same order.  x_opt / f_opt: the optimum the solve starts next to and the
+ * cost there, as the caller's entry point derived them. */
+template <bool IN_LOG_SPACE>
+PSD_COLD_DEV double newton_with_bracket(Coef c, double x_opt, double f_opt, double level) {
+  struct Side { /* the iterate nearest to the root on one side, and its residual */
+    double f, x;
+  };
+  Side above = {PSD_INF, PSD_INF}, below = {-PSD_INF, PSD_INF};
+  if (f_opt < 0) { /* (the optimum's cost as it is, not its residual: fpl:90,152) */
+    below.f = f_opt;
+    below.x = x_opt;
   } else {
-    closest_positive_cost = optimal_cost;
-    closest_positive_mean = optimal_mean;
+    above.f = f_opt;
+    above.x = x_opt;
   }
-  int step = 0;
-  do {
-    candidate_cost = poisson_loss(c, candidate_root) - equals;
-    if (0 < candidate_cost && candidate_cost < closest_positive_cost) {
-      closest_positive_cost = candidate_cost;
-      closest_positive_mean = candidate_root;
+  auto residual = [&](double x, double &slope) -> double {
+    if (IN_LOG_SPACE) {
+      const double lin = (x == -PSD_INF) ? 0.0 : c.Linear * d_exp(x);
+      const double lg = (c.Log == 0) ? 0.0 : c.Log * x;
+      slope = lin + c.Log;
+      return (lin + lg + c.Constant) - level;
     }
-    if (closest_negative_cost < candidate_cost && candidate_cost < 0) {
-      closest_negative_cost = candidate_cost;
-      closest_negative_mean = candidate_root;
+    slope = c.Linear + c.Log / x; /* PoissonDeriv fpl:63-65 */
+    return poisson_loss(c, x) - level;
+  };
+  double x = IN_LOG_SPACE ? x_opt - 1 : x_opt + 1;
+  for (int trip = 1;; trip++) {
+    double slope;
+    const double f = residual(x, slope);
+    if (0 < f && f < above.f) {
+      above.f = f;
+      above.x = x;
     }
-    if (NEWTON_STEPS <= ++step) {
-      double between_closest = (closest_positive_mean + closest_negative_mean) / 2;
-      double between_cost = poisson_loss(c, between_closest) - equals;
-      if (absd(between_cost) < absd(candidate_cost)) {
-        return d_log(between_closest);
-      } else {
-        return d_log(candidate_root);
-      }
+    if (below.f < f && f < 0) {
+      below.f = f;
+      below.x = x;
     }
-    deriv = c.Linear + c.Log / candidate_root; /* PoissonDeriv fpl:63-65 */
-    candidate_root = candidate_root - candidate_cost / deriv;
-  } while (NEWTON_EPSILON < absd(candidate_cost));
-  return d_log(candidate_root);
+    if (NEWTON_STEPS <= trip) {
+      const double mid = (above.x + below.x) / 2;
+      double unused;
+      const double f_mid = residual(mid, unused);
+      const double best = (absd(f_mid) < absd(f)) ? mid : x;
+      return IN_LOG_SPACE ? best : d_log(best);
+    }
+    if (IN_LOG_SPACE) {
+      const double step = f / slope;
+      x = x - step;
+    } else {
+      x = x - f / slope;
+    }
+    if (!(NEWTON_EPSILON < absd(f))) return IN_LOG_SPACE ? x : d_log(x);
+  }
 }
 
 /* fpl:69-127: larger root, returned as a log-mean.
@@ -291,7 +312,7 @@ PSD_D double get_larger_root(const Coef &c, const PieceOpt &o, double max_log_me
     candidate_root = candidate_root - candidate_cost / deriv;
   } while (NEWTON_EPSILON < absd(candidate_cost) && step < NEWTON_STEPS);
   if (NEWTON_STEPS <= step || rare != 0)
-    return larger_root_full(c, optimal_mean, optimal_cost, equals);
+    return newton_with_bracket<false>(c, optimal_mean, optimal_cost, equals);
 #else
   do {
     candidate_cost = poisson_loss(c, candidate_root) - equals;
@@ -299,12 +320,12 @@ PSD_D double get_larger_root(const Coef &c, const PieceOpt &o, double max_log_me
     double deriv = c.Linear + c.Log / candidate_root; /* PoissonDeriv fpl:63-65 */
     candidate_root = candidate_root - candidate_cost / deriv;
   } while (NEWTON_EPSILON < absd(candidate_cost) && step < NEWTON_STEPS);
-  if (NEWTON_STEPS <= step) return larger_root_full(c, optimal_mean, optimal_cost, equals);
+  if (NEWTON_STEPS <= step) return newton_with_bracket<false>(c, optimal_mean, optimal_cost, equals);
 #endif
 #else
   do {
     candidate_cost = poisson_loss(c, candidate_root) - equals;
-    if (NEWTON_STEPS <= ++step) return larger_root_full(c, optimal_mean, optimal_cost, equals);
+    if (NEWTON_STEPS <= ++step) return newton_with_bracket<false>(c, optimal_mean, optimal_cost, equals);
     double deriv = c.Linear + c.Log / candidate_root; /* PoissonDeriv fpl:63-65 */
     candidate_root = candidate_root - candidate_cost / deriv;
   } while (NEWTON_EPSILON < absd(candidate_cost));
@@ -312,49 +333,6 @@ PSD_D double get_larger_root(const Coef &c, const PieceOpt &o, double max_log_me
   if (steps_out) *steps_out = step;
   if (rare_out) return d_log_nb(candidate_root, *rare_out); /* (see StepMath) */
   return d_log(candidate_root);
-}
-
-/* fpl:129-190 in full: Newton in log-mean space from argmin-1, with the bracket fallback. */
-PSD_COLD_DEV double smaller_root_full(Coef c, double optimal_log_mean, double optimal_cost,
-                                      double equals) {
-  double candidate_root = optimal_log_mean - 1;
-  double candidate_cost, deriv;
-  double closest_positive_cost = PSD_INF, closest_positive_log_mean = PSD_INF;
-  double closest_negative_cost = -PSD_INF, closest_negative_log_mean = PSD_INF;
-  if (optimal_cost < 0) {
-    closest_negative_cost = optimal_cost;
-    closest_negative_log_mean = optimal_log_mean;
-  } else {
-    closest_positive_cost = optimal_cost;
-    closest_positive_log_mean = optimal_log_mean;
-  }
-  int step = 0;
-  do {
-    double linear_term = (candidate_root == -PSD_INF) ? 0.0 : c.Linear * d_exp(candidate_root);
-    double log_term = (c.Log == 0) ? 0.0 : c.Log * candidate_root;
-    candidate_cost = (linear_term + log_term + c.Constant) - equals;
-    if (0 < candidate_cost && candidate_cost < closest_positive_cost) {
-      closest_positive_cost = candidate_cost;
-      closest_positive_log_mean = candidate_root;
-    }
-    if (closest_negative_cost < candidate_cost && candidate_cost < 0) {
-      closest_negative_cost = candidate_cost;
-      closest_negative_log_mean = candidate_root;
-    }
-    if (NEWTON_STEPS <= ++step) {
-      double between_closest = (closest_positive_log_mean + closest_negative_log_mean) / 2;
-      double between_cost = get_cost(c, between_closest) - equals;
-      if (absd(between_cost) < absd(candidate_cost)) {
-        return between_closest;
-      } else {
-        return candidate_root;
-      }
-    }
-    deriv = linear_term + c.Log;
-    double offset = candidate_cost / deriv;
-    candidate_root = candidate_root - offset;
-  } while (NEWTON_EPSILON < absd(candidate_cost));
-  return candidate_root;
 }
 
 /* fpl:129-190: smaller root (a log-mean).
@@ -386,7 +364,7 @@ PSD_D double get_smaller_root(const Coef &c, const PieceOpt &o, double min_log_m
     candidate_cost = (linear_term + log_term + c.Constant) - equals;
 #ifdef PSD_NEWTON_EXIT_IN_LOOP
     if (NEWTON_STEPS <= ++step)
-      return smaller_root_full(c, optimal_log_mean, optimal_cost, equals);
+      return newton_with_bracket<true>(c, optimal_log_mean, optimal_cost, equals);
 #else
     ++step; /* the step cap ends the loop; see get_larger_root */
 #endif
@@ -402,7 +380,7 @@ PSD_D double get_smaller_root(const Coef &c, const PieceOpt &o, double min_log_m
 #else
   if (NEWTON_STEPS <= step)
 #endif
-    return smaller_root_full(c, optimal_log_mean, optimal_cost, equals);
+    return newton_with_bracket<true>(c, optimal_log_mean, optimal_cost, equals);
 #endif
   if (steps_out) *steps_out = step;
   return candidate_root;

@@ -14,6 +14,12 @@ constexpr int N_PROF = 24; /* PSD_PROFILE builds: cycle counters per wave */
  * wave's last chunk stays a small fraction of the arena. */
 constexpr int ARENA_CHUNK_LOG2_MAX = 16;
 constexpr int ARENA_CHUNK_LOG2_MIN = 10;
+/* ... and is made of blocks of 2^ar_block_log2 pieces, each a device allocation of its own; the
+ * host picks the block size per set (an eighth of its first estimate).  The checkpointed store
+ * keeps a wave's whole region in one block and may need larger ones. */
+constexpr int ARENA_BLOCK_LOG2_MIN = 19;
+constexpr int ARENA_BLOCK_LOG2_MAX = 24;
+constexpr int ARENA_BLOCK_LOG2_CKPT_MAX = 30;
 constexpr int FN_COUNT_BITS = 24;     /* fn_ref = (arena offset << 24) | piece count */
 /* merged-interval table entries pack (piece of f1 << 16) | piece of f2 into an int */
 constexpr int SPILL_CAP_MAX = 32767;
@@ -47,6 +53,8 @@ struct ProbResult {
   int spill_steps;        /* data points processed with the lists in the HBM spill area */
   int parked;             /* PST_ARENA_FULL: the state before data point step_reached is in the
                              problem's park slot, the problem can be resumed there */
+  int max_spin;           /* -DPSD_SPIN_STATS builds: largest poll count of a wait between waves */
+  long long cycles;       /* shader cycles the workgroup ran (this launch) */
 };
 
 struct DeviceArgs {
@@ -70,17 +78,29 @@ struct DeviceArgs {
   const double *contig_max_log_mean;
   const int *count;  /* 4th bedGraph column */
   const int *weight; /* chromEnd - chromStart */
-  /* arena: the in-HBM cost-function store.  Three arrays at fixed addresses for the life of the
-   * set: the host reserves address space for the largest arena the device could hold and maps
-   * memory behind it as needed (HIP virtual memory management), so that a solve which runs out
-   * of room can be continued after MORE memory has been mapped at the arena's end -- nothing
-   * is copied, no record moves, the kernel's addressing never changes.  The kernel parks the
-   * problems that ran out (their two live functions go to the problem's park slot) and the
-   * host relaunches those problems only, from the data point they had reached. */
-  double *ar_mx;
-  double *ar_prv;
-  int *ar_di;
-  unsigned long long ar_cap; /* pieces (mapped) */
+  /* arena: the in-HBM cost-function store, made of BLOCKS of 2^ar_block_log2 pieces.  Every
+   * block is a device allocation (an address range) of its own, laid out
+   *   [max_log_mean f64 x B][prev_log_mean f64 x B][data_i i32 x B]      (20 bytes per piece),
+   * and the host can add blocks WHILE THE KERNEL RUNS: memory mapped behind an address range of
+   * its own is visible to a running kernel (tools/vmm_block_probe.cpp; mapping behind a range
+   * the kernel already uses waits for the kernel, tools/vmm_overlap_probe.cpp).  A piece offset
+   * is (block << ar_block_log2) | index; chunks and function records never straddle a block.
+   *   ar_block  device table of block base addresses: filled by the host for the blocks that
+   *             exist at launch, by the wave that first takes a chunk of a later block for those
+   *             (from ar_live), so that the decoding finds every block of its own problem there
+   *   ar_cap    pieces mapped when the kernel was launched
+   *   ar_live   pinned host memory (nullptr: the arena cannot grow during the launch):
+   *             [0] pieces mapped by now, [1] != 0: no more will come, [2 + b] base of block b
+   *   ar_used   pinned host word: high-water mark of the pieces handed out (the host maps ahead
+   *             of it)
+   * A wave that still finds no room parks its problem (its two live functions go to the
+   * problem's park slot) and the host relaunches those problems only, from the data point they
+   * had reached, after adding blocks. */
+  char **ar_block;
+  int ar_block_log2;
+  unsigned long long ar_cap;
+  const unsigned long long *ar_live;
+  unsigned long long *ar_used;
   /* per problem: the data point to resume at after a regrowth (0: from the start); nullptr when
    * the set has no park slots */
   const int *prob_resume;

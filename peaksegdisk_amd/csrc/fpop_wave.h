@@ -109,18 +109,40 @@ struct SharedBlock {
 #ifdef PSD_PROFILE
   long long prof[4][N_PROF];
 #endif
+#ifdef PSD_SPIN_STATS
+  int spin_max[4];
+#endif
 };
 
 PSD_LDS SharedBlock g_sm;
 
+/* Waits between the waves of a workgroup (the flag barrier of a data point, the helper
+ * mailboxes, the progress word of a shared envelope) poll an LDS word at most this many times:
+ * a wave that never comes turns into an error status instead of a hang.  A poll with its pause
+ * is ~100 cycles, so the bound is seconds; the slowest legitimate wait is four orders of
+ * magnitude shorter (tests/test_gpu_round4.py measures it with -DPSD_SPIN_STATS). */
+constexpr int WAIT_SPIN_LIMIT = 1 << 26;
+#ifdef PSD_SPIN_STATS
+#define PSD_SPIN_NOTE(spin)                                                           \
+  do {                                                                                \
+    if (lane_id() == 0 && (spin) > g_sm.spin_max[wave_id()]) g_sm.spin_max[wave_id()] = (spin); \
+  } while (0)
+#else
+#define PSD_SPIN_NOTE(spin) \
+  do {                      \
+  } while (0)
+#endif
 #ifdef PSD_HELPER_WAVES
-constexpr int MAIL_SPIN_LIMIT = 1 << 26;
+constexpr int MAIL_SPIN_LIMIT = WAIT_SPIN_LIMIT;
 /* main wave: wait until the helper has finished the last posted command */
 PSD_D bool mail_wait(int chain) {
   Mail &m = g_sm.mail[chain];
   const int want = flag_load(&m.seq_cmd);
   for (int spin = 0; spin < MAIL_SPIN_LIMIT; spin++) {
-    if (flag_load(&m.seq_done) == want) return true;
+    if (flag_load(&m.seq_done) == want) {
+      PSD_SPIN_NOTE(spin);
+      return true;
+    }
     spin_pause();
   }
   return false;
@@ -1741,7 +1763,7 @@ PSD_D void helper_loop(int chain, const DeviceArgs &a) {
     int cmd = seen;
     for (int spin = 0;; spin++) {
       cmd = flag_load(&m.seq_cmd);
-      if (cmd != seen) break;
+      if (cmd != seen) break; /* (not a wait FOR a wave at work: the helper idles here) */
       if (spin > MAIL_SPIN_LIMIT || flag_load(&m.abort)) return;
       spin_pause();
     }
@@ -2289,6 +2311,7 @@ PSD_D int min_env_coop(L f1_, int n1_, L f2_, int n2_, L out_, int cap_, S s_, i
       for (int spin = 0; spin < MAIL_SPIN_LIMIT; spin++) {
         if (rdlane_i(flag_load(&m.h_progress), 0) >= want) {
           there = true;
+          PSD_SPIN_NOTE(spin);
           break;
         }
         spin_pause();

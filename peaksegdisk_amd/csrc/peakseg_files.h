@@ -247,14 +247,18 @@ int solve_files(int n, FileProblem *fps) {
   std::vector<Coverage> covs;
   std::map<std::string, int> cov_of_path;
   std::map<std::string, int> cov_status;
-  /* A (bedGraph, penalty string) pair listed twice names the same two output files: the second
-   * copy is not solved (its writer thread would race the first one's on the same paths); it
-   * receives the first one's status and figures at the end. */
+  /* A (bedGraph, penalty string) pair listed twice names the same two output files -- the
+   * reference builds the names from the path string as given (drv:212-223) -- so the second copy
+   * is not processed at all (its writer thread would race the first one's on the same paths);
+   * it receives the first one's status and figures at the end.  Two DIFFERENT strings that reach
+   * the same file (a symlinked coverage.bedGraph, as in PeakSegPipeline problem directories)
+   * name different output files: each entry gets its own, but the file is parsed once and the
+   * dynamic program of a (file, penalty) pair runs once (step 3). */
   std::vector<int> dup_of((size_t)n, -1);
   {
     std::map<std::pair<std::string, std::string>, int> seen;
     for (int i = 0; i < n; i++) {
-      auto key = std::make_pair(real_path(fps[i].bedGraph), std::string(fps[i].penalty_str));
+      auto key = std::make_pair(std::string(fps[i].bedGraph), std::string(fps[i].penalty_str));
       auto it = seen.find(key);
       if (it == seen.end()) {
         seen[key] = i;
@@ -269,7 +273,7 @@ int solve_files(int n, FileProblem *fps) {
     if (dup_of[(size_t)i] >= 0) continue;
     fp.status = parse_penalty(fp.penalty_str, fp.is_Inf, fp.penalty);
     if (fp.status) continue;
-    std::string path = fp.bedGraph;
+    const std::string path = real_path(fp.bedGraph); /* one parse per file, whatever its names */
     auto it = cov_of_path.find(path);
     if (it == cov_of_path.end()) {
       Coverage cv;
@@ -304,6 +308,7 @@ int solve_files(int n, FileProblem *fps) {
     std::vector<int> contig_n, prob_contig;
     std::vector<const int *> cnt_ptr, wt_ptr;
     std::vector<double> prob_pen;
+    std::map<std::pair<int, std::string>, int> dp_of; /* (file, penalty string) -> device problem */
     for (int i : dp) {
       FileProblem &fp = fps[i];
       if (contig_of_cov[(size_t)fp.cov] < 0) {
@@ -313,7 +318,14 @@ int solve_files(int n, FileProblem *fps) {
         cnt_ptr.push_back(cv.count.data());
         wt_ptr.push_back(cv.weight.data());
       }
+      auto key = std::make_pair(fp.cov, std::string(fp.penalty_str));
+      auto it = dp_of.find(key);
+      if (it != dp_of.end()) { /* the same file under another name: its problem is there already */
+        fp.dp_index = it->second;
+        continue;
+      }
       fp.dp_index = (int)prob_contig.size();
+      dp_of[key] = fp.dp_index;
       prob_contig.push_back(contig_of_cov[(size_t)fp.cov]);
       prob_pen.push_back(fp.penalty);
     }
@@ -329,12 +341,12 @@ int solve_files(int n, FileProblem *fps) {
     lap("kernel");
     /* results leave the device one problem after the other; the text files (the segment
      * tables of a penalty grid are hundreds of MB) are then formatted by a few threads */
-    std::vector<DpFetched> fetched(dp.size());
-    for (size_t k = 0; k < dp.size(); k++) {
+    std::vector<DpFetched> fetched(prob_contig.size());
+    for (size_t k = 0; k < fetched.size(); k++) {
       if (st) {
         fetched[k].status = st;
       } else {
-        fetch_dp(fps[dp[k]].dp_index, set, fetched[k]);
+        fetch_dp((int)k, set, fetched[k]);
       }
     }
     if (set) peakseg_hip_problem_set_destroy(set);
@@ -343,7 +355,7 @@ int solve_files(int n, FileProblem *fps) {
     auto writer = [&]() {
       for (size_t k = next_k++; k < dp.size(); k = next_k++) {
         FileProblem &fp = fps[dp[k]];
-        fp.status = write_dp_outputs(fp, covs[(size_t)fp.cov], fetched[k]);
+        fp.status = write_dp_outputs(fp, covs[(size_t)fp.cov], fetched[(size_t)fp.dp_index]);
       }
     };
     unsigned n_threads = std::thread::hardware_concurrency();

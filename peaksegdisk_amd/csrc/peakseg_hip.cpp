@@ -99,6 +99,19 @@ void set_error(const char *fmt, ...) {
   g_last_error = buf;
 }
 
+/* Things a caller may want to know about a call that SUCCEEDED (a wait that ran into its bound,
+ * a fallback taken): kept apart from the error text, which describes failures only. */
+thread_local std::string g_last_warning;
+void set_warning(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_warning = buf;
+  if (getenv("PEAKSEG_HIP_TIMING")) fprintf(stderr, "peakseg_hip warning: %s\n", buf);
+}
+
 void emit_text(const char *fmt, ...) {
   char buf[512];
   va_list ap;
@@ -292,21 +305,26 @@ struct psd_problem_set {
   int n_lat_mixed = 0;     /* mixed launch: this many (longest) problems ran on the latency build */
   std::vector<int> order;  /* problems, longest contig first */
   bool can_park = false;   /* the set has a park slot per problem (full store) */
-  /* the arena's three arrays: address space reserved once (vmm), memory mapped behind it in
-   * steps; or, without virtual memory management, plain allocations that growing copies */
-  bool arena_vmm = false;
-  unsigned long long arena_reserved = 0; /* pieces of address space per array */
-  unsigned long long arena_block = 0;    /* pieces per mapping: every mapping of a range has the
-                                            size of the first one (the runtime refuses
-                                            hipMemSetAccess on ranges mapped in unequal sizes) */
-  struct ArenaMap {
-    int array; /* 0 mx, 1 prv, 2 di */
-    size_t offset, bytes;
+  /* The arena: blocks of 2^ar_block_log2 pieces, each a device allocation of its own (an
+   * address range reserved, created, mapped and given access by the virtual-memory API; plain
+   * hipMalloc without it).  Blocks can be added while a kernel runs (fpop_types.h), which is
+   * what grow_arena_live() does from a second host thread during a solve. */
+  struct ArenaBlock {
+    void *base = nullptr;
+    bool vmm = false;
 #ifndef PSD_EMU
-    hipMemGenericAllocationHandle_t handle;
+    hipMemGenericAllocationHandle_t handle{};
 #endif
   };
-  std::vector<ArenaMap> arena_maps;
+  std::vector<ArenaBlock> arena_blocks;
+  bool arena_vmm = false;
+  size_t table_cap = 0;              /* entries of the two block tables */
+  size_t table_synced = 0;           /* blocks whose address is in the device table */
+  unsigned long long *h_live = nullptr; /* pinned: [0] pieces mapped, [1] final, [2 + b] bases */
+  unsigned long long *h_used = nullptr; /* pinned: pieces handed out (kernel -> host) */
+  bool live_growth = false;          /* this set's arena grows while its kernel runs */
+  unsigned long long first_estimate = 0; /* pieces the set was first sized for */
+  unsigned long long live_blocks_added = 0; /* blocks the last solve added under its kernels */
   int *d_resume = nullptr; /* device copy of resume_t */
   int *d_order_sub = nullptr; /* launch order of a relaunch: the unfinished problems */
   std::vector<int> resume_t;  /* per problem: data point to resume at (0: from the start) */
@@ -316,6 +334,13 @@ struct psd_problem_set {
   hipEvent_t ev2 = nullptr;
   int *started = nullptr; /* pinned host word: latency-build workgroups of a mixed launch */
   bool mixed_wait_timed_out = false; /* the wait for them ran into its bound once: recorded, not repeated */
+  /* the segment tables packed at their exact sizes (peakseg_hip_problem_set_pack_tables) */
+  int *d_pack_start = nullptr;
+  double *d_pack_mean = nullptr;
+  long long *d_pack_rows = nullptr; /* per problem: first packed row, row count, source offset */
+  long long pack_capacity = 0, pack_total = -1;
+  int parks = 0;                          /* problems parked by the last solve's launches */
+  unsigned long long park_pool_pieces = 0; /* ... and what they took from the overflow pool */
   std::vector<void *> allocs;
   unsigned long long bytes = 0;
 };
@@ -387,198 +412,223 @@ unsigned long long arena_fit(psd_problem_set *s) {
 }
 
 
-/* release the arena: mappings and address space (vmm) or the allocations */
+size_t arena_block_bytes(const psd_problem_set *s) { return (size_t)20 << s->d.ar_block_log2; }
+unsigned long long arena_mapped(const psd_problem_set *s) {
+  return (unsigned long long)s->arena_blocks.size() << s->d.ar_block_log2;
+}
+
+/* release the arena: every block, and the block tables */
 void free_arena(psd_problem_set *s) {
+  const size_t bytes = arena_block_bytes(s);
+  for (auto &b : s->arena_blocks) {
+#ifndef PSD_EMU
+    if (b.vmm) {
+      (void)hipMemUnmap(b.base, bytes);
+      (void)hipMemRelease(b.handle);
+      (void)hipMemAddressFree(b.base, bytes);
+    } else
+#endif
+    {
+      (void)hipFree(b.base);
+    }
+    s->bytes -= bytes;
+  }
+  s->arena_blocks.clear();
+  if (s->d.ar_block) {
+    forget_alloc(s, s->d.ar_block);
+    (void)hipFree(s->d.ar_block);
+    s->bytes -= s->table_cap * sizeof(char *);
+    s->d.ar_block = nullptr;
+  }
+  if (s->h_live) (void)hipHostFree(s->h_live);
+  if (s->h_used) (void)hipHostFree(s->h_used);
+  s->h_live = s->h_used = nullptr;
+  s->table_cap = s->table_synced = 0;
+  s->d.ar_cap = 0;
+  s->arena_pieces = 0;
+}
+
+/* One more block.  Safe while a kernel of this set runs: nothing the kernel uses is touched,
+ * the block is published through the pinned words (address first, then the capacity). */
+int arena_add_block(psd_problem_set *s) {
+  if (s->arena_blocks.size() >= s->table_cap) {
+    set_error("cost-function arena: block table of %zu entries is full", s->table_cap);
+    return ERROR_DEVICE_MEMORY;
+  }
+  const size_t bytes = arena_block_bytes(s);
+  psd_problem_set::ArenaBlock b;
+  const char *what = "hipMalloc";
+  hipError_t e = hipSuccess;
 #ifndef PSD_EMU
   if (s->arena_vmm) {
-    void *base[3] = {s->d.ar_mx, s->d.ar_prv, s->d.ar_di};
-    const size_t esz[3] = {8, 8, 4};
-    for (auto &m : s->arena_maps) {
-      (void)hipMemUnmap((char *)base[m.array] + m.offset, m.bytes);
-      (void)hipMemRelease(m.handle);
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = s->device;
+    hipMemAccessDesc acc = {};
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = s->device;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    b.vmm = true;
+    what = "hipMemAddressReserve";
+    e = hipMemAddressReserve(&b.base, bytes, (size_t)2 << 20, nullptr, 0);
+    if (e == hipSuccess) {
+      what = "hipMemCreate";
+      e = hipMemCreate(&b.handle, bytes, &prop, 0);
+      if (e == hipSuccess) {
+        what = "hipMemMap";
+        e = hipMemMap(b.base, bytes, 0, b.handle, 0);
+        if (e == hipSuccess) {
+          what = "hipMemSetAccess";
+          e = hipMemSetAccess(b.base, bytes, &acc, 1);
+          if (e != hipSuccess) (void)hipMemUnmap(b.base, bytes);
+        }
+        if (e != hipSuccess) (void)hipMemRelease(b.handle);
+      }
+      if (e != hipSuccess) (void)hipMemAddressFree(b.base, bytes);
     }
-    s->arena_maps.clear();
-    for (int q = 0; q < 3; q++)
-      if (base[q]) (void)hipMemAddressFree(base[q], (size_t)s->arena_reserved * esz[q]);
-    s->arena_vmm = false;
-    s->arena_reserved = 0;
   } else
 #endif
   {
-    void *ptrs[3] = {s->d.ar_mx, s->d.ar_prv, s->d.ar_di};
-    for (void *q : ptrs) {
-      if (!q) continue;
-      forget_alloc(s, q);
-      (void)hipFree(q);
-    }
+    e = hipMalloc(&b.base, bytes);
   }
-  s->bytes -= s->d.ar_cap * 20ull;
-  s->d.ar_mx = s->d.ar_prv = nullptr;
-  s->d.ar_di = nullptr;
-  s->d.ar_cap = 0;
-}
-
-#ifndef PSD_EMU
-/* Reserve address space for the largest arena this device could ever hold (its whole memory),
- * for each of the three arrays.  False when virtual memory management is not available. */
-bool arena_reserve(psd_problem_set *s) {
-  if (getenv("PEAKSEG_HIP_NO_VMM")) return false;
-  int vmm = 0;
-  if (hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, s->device) !=
-          hipSuccess ||
-      !vmm)
-    return false;
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return false;
-  unsigned long long pieces = (unsigned long long)total_b / 20ull;
-  pieces = (pieces + 0xfffffull) & ~0xfffffull; /* whole mebi-pieces: any granularity divides it */
-  void *base[3] = {nullptr, nullptr, nullptr};
-  const size_t esz[3] = {8, 8, 4};
-  for (int q = 0; q < 3; q++) {
-    if (hipMemAddressReserve(&base[q], (size_t)pieces * esz[q], (size_t)2 << 20, nullptr, 0) != hipSuccess) {
-      for (int r = 0; r < q; r++) (void)hipMemAddressFree(base[r], (size_t)pieces * esz[r]);
-      (void)hipGetLastError();
-      return false;
-    }
+  if (e != hipSuccess) {
+    set_error("cost-function arena: block %zu of %zu bytes failed in %s: %s", s->arena_blocks.size(),
+              bytes, what, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return ERROR_DEVICE_MEMORY;
   }
-  s->d.ar_mx = (double *)base[0];
-  s->d.ar_prv = (double *)base[1];
-  s->d.ar_di = (int *)base[2];
-  s->arena_reserved = pieces;
-  s->arena_vmm = true;
-  return true;
-}
-
-/* map memory behind pieces [from, to) of the three arrays */
-int arena_map_more(psd_problem_set *s, unsigned long long from, unsigned long long to) {
-  hipMemAllocationProp prop = {};
-  prop.type = hipMemAllocationTypePinned;
-  prop.location.type = hipMemLocationTypeDevice;
-  prop.location.id = s->device;
-  hipMemAccessDesc acc = {};
-  acc.location.type = hipMemLocationTypeDevice;
-  acc.location.id = s->device;
-  acc.flags = hipMemAccessFlagsProtReadWrite;
-  void *base[3] = {s->d.ar_mx, s->d.ar_prv, s->d.ar_di};
-  const size_t esz[3] = {8, 8, 4};
-  const size_t first_new = s->arena_maps.size();
-  for (int q = 0; q < 3; q++) {
-    psd_problem_set::ArenaMap m;
-    m.array = q;
-    m.offset = (size_t)from * esz[q];
-    m.bytes = (size_t)(to - from) * esz[q];
-    const char *what = "hipMemCreate";
-    hipError_t e = hipMemCreate(&m.handle, m.bytes, &prop, 0);
-    if (e == hipSuccess) {
-      what = "hipMemMap";
-      e = hipMemMap((char *)base[q] + m.offset, m.bytes, 0, m.handle, 0);
-      if (e == hipSuccess) {
-        what = "hipMemSetAccess";
-        e = hipMemSetAccess((char *)base[q] + m.offset, m.bytes, &acc, 1);
-        if (e != hipSuccess) (void)hipMemUnmap((char *)base[q] + m.offset, m.bytes);
-      }
-      if (e != hipSuccess) (void)hipMemRelease(m.handle);
-    }
-    if (e != hipSuccess) {
-      set_error("mapping %zu more bytes of arena at %p + %zu failed in %s: %s", m.bytes, base[q],
-                m.offset, what, hipGetErrorString(e));
-      (void)hipGetLastError();
-      while (s->arena_maps.size() > first_new) { /* undo this step's mappings */
-        auto &u = s->arena_maps.back();
-        (void)hipMemUnmap((char *)base[u.array] + u.offset, u.bytes);
-        (void)hipMemRelease(u.handle);
-        s->arena_maps.pop_back();
-      }
-      return ERROR_DEVICE_MEMORY;
-    }
-    s->arena_maps.push_back(m);
-  }
+  s->arena_blocks.push_back(b);
+  s->bytes += bytes;
+  const size_t k = s->arena_blocks.size() - 1;
+  __atomic_store_n(&s->h_live[2 + k], (unsigned long long)(uintptr_t)b.base, __ATOMIC_RELAXED);
+  __atomic_store_n(&s->h_live[0], arena_mapped(s), __ATOMIC_RELEASE);
   return 0;
 }
-#endif
 
-/* Give the arena `pieces` pieces in all: the first allocation, or growth.  Growth keeps every
- * record where it is -- more memory is mapped at the end of the reserved address range; without
- * virtual memory management the arrays are re-allocated and copied -- so a solve that ran out
- * of room is resumed, not repeated. */
-int alloc_arena(psd_problem_set *s, unsigned long long pieces) {
-  const bool first = s->d.ar_cap == 0;
+/* between launches: the device table learns the blocks added since, DeviceArgs the capacity */
+int arena_sync_table(psd_problem_set *s) {
+  const size_t n = s->arena_blocks.size();
+  if (n > s->table_synced) {
+    std::vector<char *> bases;
+    for (size_t k = s->table_synced; k < n; k++) bases.push_back((char *)s->arena_blocks[k].base);
+    HIP_TRY(hipMemcpy(s->d.ar_block + s->table_synced, bases.data(), bases.size() * sizeof(char *),
+                      hipMemcpyHostToDevice));
+    s->table_synced = n;
+  }
+  s->d.ar_cap = arena_mapped(s);
+  s->arena_pieces = s->d.ar_cap;
+  return 0;
+}
+
+/* Give the arena at least `pieces` pieces in all, never more than `limit` (0: no limit): the
+ * first allocation, or growth between launches.  Growth adds blocks: no record moves, so a
+ * solve that ran out of room is resumed, not repeated. */
+int alloc_arena(psd_problem_set *s, unsigned long long pieces, unsigned long long limit = 0,
+                bool starter_only = false) {
+  const bool first = s->arena_blocks.empty() && s->d.ar_block == nullptr;
   const unsigned long long n_waves = 2ull * (unsigned long long)s->n_problems;
-  int lg = s->d.ar_chunk_log2;
   if (first) {
     /* chunk size: about a sixteenth of what one wave will store, within [2^10, 2^16] pieces */
-    lg = psd::ARENA_CHUNK_LOG2_MIN;
+    int lg = psd::ARENA_CHUNK_LOG2_MIN;
     while (lg < psd::ARENA_CHUNK_LOG2_MAX && (pieces / n_waves) >> (lg + 5)) lg++;
-  }
-  const unsigned long long chunk = 1ull << lg;
-  /* whole chunks, and at least two per wave so that nobody starves at start-up */
-  unsigned long long min_pieces = chunk * 2ull * n_waves;
-  if (pieces < min_pieces) pieces = min_pieces;
-  pieces = (pieces + chunk - 1) / chunk * chunk;
-  if (pieces <= s->d.ar_cap) return 0;
-#ifndef PSD_EMU
-  if (first && !s->arena_vmm) (void)arena_reserve(s);
-  if (s->arena_vmm) {
-    /* Mappings are whole blocks of one size, an eighth of the first allocation (a multiple of
-     * 2^19 pieces: 2 MiB of the int array): measured on ROCm 7.2 / gfx950, hipMemSetAccess
-     * refuses ranges mapped in unequal sizes or at offsets finer than 2 MiB, although the
-     * reported granularity is 4 KiB (tools/vmm_probe.cpp).  Eight blocks, so that growth comes
-     * in steps of an eighth: memory that was used before costs 13-25 ms per GB to get
-     * (profiles/r03/probe_results.log), whether mapped or hipMalloc'ed. */
-    if (first) s->arena_block = ((pieces + 7ull) / 8ull + 0x7ffffull) & ~0x7ffffull;
-    const unsigned long long blk = s->arena_block;
-    pieces = (pieces + blk - 1) / blk * blk;
-    if (pieces > s->arena_reserved) pieces = s->arena_reserved / blk * blk;
-    for (unsigned long long at = s->d.ar_cap; at < pieces; at += blk) {
-      int st = arena_map_more(s, at, at + blk);
-      if (st) {
-        if (at == s->d.ar_cap) return st;
-        pieces = at; /* keep what could be mapped */
-        break;
-      }
-      s->bytes += blk * 20ull;
-    }
-    s->d.ar_cap = pieces;
     s->d.ar_chunk_log2 = lg;
-    s->arena_pieces = pieces;
-    return 0;
-  }
-#endif
-  /* plain allocations; growing = allocate, copy what has been written, free */
-  double *mx = nullptr, *prv = nullptr;
-  int *di = nullptr;
-  int st;
-  if ((st = dev_alloc(s, &mx, pieces)) || (st = dev_alloc(s, &prv, pieces)) ||
-      (st = dev_alloc(s, &di, pieces))) {
-    void *got[3] = {mx, prv, di};
-    const size_t sz[3] = {8, 8, 4};
-    for (int q = 0; q < 3; q++)
-      if (got[q]) {
-        forget_alloc(s, got[q]);
-        (void)hipFree(got[q]);
-        s->bytes -= pieces * sz[q];
+    /* block size: about an eighth of the first estimate, within [2^19, 2^24] pieces (10 MB to
+     * 336 MB; 2^19 pieces make the int array 2 MiB, the granularity the virtual-memory calls
+     * accept on ROCm 7.2); the checkpointed store needs a wave's region inside one block */
+    int blg = psd::ARENA_BLOCK_LOG2_MIN;
+    while (blg < psd::ARENA_BLOCK_LOG2_MAX && (pieces >> (blg + 3))) blg++;
+    bool small_blocks = false;
+    if (const char *e = getenv("PEAKSEG_HIP_ARENA_BLOCK_LOG2")) {
+      /* tests: blocks smaller than the virtual-memory granularity come from hipMalloc */
+      const int v = atoi(e);
+      if (v >= lg && v >= 10 && v <= psd::ARENA_BLOCK_LOG2_MAX) {
+        blg = v;
+        small_blocks = v < psd::ARENA_BLOCK_LOG2_MIN;
       }
-    return st;
-  }
-  if (!first) {
-    const size_t n = (size_t)s->d.ar_cap;
-    HIP_TRY(hipMemcpy(mx, s->d.ar_mx, n * 8, hipMemcpyDeviceToDevice));
-    HIP_TRY(hipMemcpy(prv, s->d.ar_prv, n * 8, hipMemcpyDeviceToDevice));
-    HIP_TRY(hipMemcpy(di, s->d.ar_di, n * 4, hipMemcpyDeviceToDevice));
-    void *old[3] = {s->d.ar_mx, s->d.ar_prv, s->d.ar_di};
-    for (void *q : old) {
-      forget_alloc(s, q);
-      (void)hipFree(q);
     }
-    s->bytes -= s->d.ar_cap * 20ull;
+    (void)small_blocks;
+    while (s->ckpt_interval > 0 && blg < psd::ARENA_BLOCK_LOG2_CKPT_MAX && (1ull << blg) < s->d.ckpt_region)
+      blg++;
+    s->d.ar_block_log2 = blg;
+#ifndef PSD_EMU
+    int vmm = 0;
+    s->arena_vmm = !getenv("PEAKSEG_HIP_NO_VMM") && !small_blocks &&
+                   hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported,
+                                         s->device) == hipSuccess && vmm != 0;
+#endif
+    /* tables for every block the device's memory could hold */
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) total_b = (size_t)288 << 30;
+    s->table_cap = (size_t)(((unsigned long long)total_b / 20ull) >> blg) + 8;
+    int st = dev_alloc(s, &s->d.ar_block, s->table_cap);
+    if (st) return st;
+    hipError_t e = hipMemset(s->d.ar_block, 0, s->table_cap * sizeof(char *));
+    if (e == hipSuccess)
+      e = hipHostMalloc((void **)&s->h_live, (2 + s->table_cap) * sizeof(unsigned long long),
+                        hipHostMallocCoherent | hipHostMallocMapped);
+    if (e == hipSuccess)
+      e = hipHostMalloc((void **)&s->h_used, 64, hipHostMallocCoherent | hipHostMallocMapped);
+    if (e != hipSuccess) {
+      set_error("cost-function arena: block tables: %s", hipGetErrorString(e));
+      return ERROR_DEVICE_MEMORY;
+    }
+    memset(s->h_live, 0, (2 + s->table_cap) * sizeof(unsigned long long));
+    s->h_live[1] = 1; /* final until a solve says otherwise */
+    *s->h_used = 0;
+    s->d.ar_live = s->h_live;
+    s->d.ar_used = s->h_used;
+    s->table_synced = 0;
   }
-  s->d.ar_mx = mx;
-  s->d.ar_prv = prv;
-  s->d.ar_di = di;
-  s->d.ar_cap = pieces;
-  s->d.ar_chunk_log2 = lg;
-  s->arena_pieces = pieces;
-  return 0;
+  const int blg = s->d.ar_block_log2;
+  const unsigned long long chunk = 1ull << s->d.ar_chunk_log2;
+  if (s->ckpt_interval > 0) {
+    /* whole regions per block (the kernel's addressing, forward_body): the caller asks for
+     * region x 2 x problems, the blocks hold a whole number of regions each */
+    if ((1ull << blg) < s->d.ckpt_region) {
+      set_error("checkpointed store: a region of %llu pieces exceeds the largest arena block (%llu)",
+                s->d.ckpt_region, 1ull << blg);
+      return ERROR_DEVICE_MEMORY;
+    }
+    const unsigned long long per_block = (1ull << blg) / s->d.ckpt_region;
+    pieces = ((n_waves + per_block - 1) / per_block) << blg;
+    if (limit && pieces > limit) {
+      /* The kernel indexes region (2 p + chain) without looking at ar_cap: an arena clipped to
+       * what fits would be written beyond its end.  The regions either fit or the set does not. */
+      set_error("checkpointed store: %llu pieces per region x %llu regions (%llu bytes) do not "
+                "fit (free HBM / PEAKSEG_HIP_MAX_BYTES)", s->d.ckpt_region, n_waves, pieces * 20ull);
+      return ERROR_DEVICE_MEMORY;
+    }
+  } else {
+    /* at least two chunks per wave so that nobody starves at start-up */
+    const unsigned long long min_pieces = chunk * 2ull * n_waves;
+    /* (live growth: just that and two blocks of headroom; the rest comes under the kernel) */
+    if (starter_only) pieces = min_pieces + (2ull << blg);
+    if (pieces < min_pieces) pieces = min_pieces;
+  }
+  unsigned long long want_blocks = (pieces + (1ull << blg) - 1) >> blg;
+  if (limit) {
+    /* a limit counts whole blocks, rounded DOWN: the cap is a hard bound for processes that
+     * share a GPU (one block at least: without it there is no arena) */
+    unsigned long long most = limit >> blg;
+    if (most < 1) most = 1;
+    if (want_blocks > most) want_blocks = most;
+  }
+  int st = 0;
+  const size_t before = s->arena_blocks.size();
+  while (s->arena_blocks.size() < want_blocks) {
+    st = arena_add_block(s);
+#ifndef PSD_EMU
+    if (st && first && s->arena_vmm && s->arena_blocks.empty()) {
+      /* the virtual-memory calls refuse on this system: plain allocations from here on */
+      s->arena_vmm = false;
+      continue;
+    }
+#endif
+    if (st) break;
+  }
+  if (st && s->arena_blocks.size() == before) return st; /* keep what could be added otherwise */
+  return arena_sync_table(s);
 }
 
 void free_spill(psd_problem_set *s) {
@@ -645,6 +695,32 @@ int alloc_ckpt_overflow(psd_problem_set *s, unsigned long long pieces) {
   return 0;
 }
 
+/* Full store: a larger overflow pool that KEEPS what parked problems have in it (they read it
+ * back when they are resumed). */
+int grow_ckpt_overflow_keep(psd_problem_set *s, unsigned long long pieces) {
+  double *f64 = nullptr;
+  int *i32 = nullptr;
+  int st;
+  if ((st = dev_alloc(s, &f64, (size_t)pieces * 6)) || (st = dev_alloc(s, &i32, (size_t)pieces))) {
+    if (f64) {
+      forget_alloc(s, f64);
+      (void)hipFree(f64);
+      s->bytes -= pieces * 48ull;
+    }
+    return st;
+  }
+  const size_t old = (size_t)s->d.ckpt_ovf_cap;
+  /* a function of n pieces at offset off: 6 n doubles from 6 off, n ints from off -- offsets
+   * are positions, not sizes, so the arrays are copied as they are */
+  HIP_TRY(hipMemcpy(f64, s->d.ckpt_ovf_f64, old * 6 * sizeof(double), hipMemcpyDeviceToDevice));
+  HIP_TRY(hipMemcpy(i32, s->d.ckpt_ovf_i32, old * sizeof(int), hipMemcpyDeviceToDevice));
+  free_ckpt_overflow(s);
+  s->d.ckpt_ovf_f64 = f64;
+  s->d.ckpt_ovf_i32 = i32;
+  s->d.ckpt_ovf_cap = pieces;
+  return 0;
+}
+
 int env_device() {
   /* which GPU the file-level entry points use: PEAKSEG_HIP_DEVICE (one process per GPU sets it
    * from its rank); default 0 */
@@ -664,6 +740,7 @@ extern "C" int peakseg_hip_device_count(void) {
 }
 
 extern "C" const char *peakseg_hip_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char *peakseg_hip_last_warning(void) { return g_last_warning.c_str(); }
 
 /* shader clock of a device in kHz (0 when unknown): bench.py turns kernel time into cycles per
  * data point with it */
@@ -677,7 +754,7 @@ extern "C" void peakseg_hip_set_print(void (*print)(const char *)) { g_print = p
 
 extern "C" void peakseg_hip_problem_set_destroy(psd_problem_set *s) {
   if (!s) return;
-  if (s->d.ar_cap || s->arena_vmm) free_arena(s);
+  free_arena(s);
   for (void *q : s->allocs) (void)hipFree(q);
   for (auto &e : s->ev)
     if (e) (void)hipEventDestroy(e);
@@ -698,6 +775,16 @@ extern "C" int peakseg_hip_problem_set_solve_stats(psd_problem_set *s, int *laun
   if (!s) return -1;
   if (launches) *launches = s->launches;
   if (steps_run) *steps_run = s->steps_run;
+  return 0;
+}
+
+extern "C" int peakseg_hip_problem_set_arena_stats(psd_problem_set *s,
+                                                   unsigned long long *block_pieces, int *blocks,
+                                                   int *blocks_added_live) {
+  if (!s) return -1;
+  if (block_pieces) *block_pieces = 1ull << s->d.ar_block_log2;
+  if (blocks) *blocks = (int)s->arena_blocks.size();
+  if (blocks_added_live) *blocks_added_live = (int)s->live_blocks_added;
   return 0;
 }
 
@@ -939,6 +1026,7 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
    * maps more and resumes the parked problems if one reports PST_ARENA_FULL. */
   s->arena_auto = arena_pieces == 0;
   unsigned long long want = arena_pieces;
+  unsigned long long first_limit = 0;
   if (K > 0) {
     /* one region per chain and problem: the records of K + 1 data points */
     /* The checkpointed store cannot park: a block whose records outgrow the region during the
@@ -956,6 +1044,7 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
     want = (unsigned long long)((double)dp_bins * 2.0 * per_fn);
     unsigned long long fit = arena_fit(s);
     if (want > fit) want = fit;
+    first_limit = fit;
   }
   if (s->max_bytes && s->bytes + want * 20ull > s->max_bytes) {
     set_error("problem set needs %llu bytes, PEAKSEG_HIP_MAX_BYTES allows %llu",
@@ -963,7 +1052,15 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
     peakseg_hip_problem_set_destroy(s);
     return ERROR_DEVICE_MEMORY;
   }
-  if ((st = alloc_arena(s, want))) {
+  /* Full store sized by the library: the arena grows WHILE the kernel runs (the host maps blocks
+   * ahead of what the waves have taken, solve()), so only the first few blocks are mapped here
+   * -- getting memory costs 13-35 ms per GB on a GPU whose memory has been used before, and
+   * that time now passes under the kernel instead of in front of it.  The estimate still picks
+   * the chunk and block sizes.  PEAKSEG_HIP_NO_LIVE_GROWTH=1: everything the estimate asks for
+   * is mapped here, and a solve that needs more parks, grows and resumes (as round 3 did). */
+  s->live_growth = K == 0 && s->arena_auto && !getenv("PEAKSEG_HIP_NO_LIVE_GROWTH");
+  s->first_estimate = want;
+  if ((st = alloc_arena(s, want, first_limit, s->live_growth))) {
     peakseg_hip_problem_set_destroy(s);
     return st;
   }
@@ -972,15 +1069,22 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
       s->n_cu <= 0)
     s->n_cu = 256;
   s->order = order;
-  hipError_t e = hipStreamCreate(&s->stream);
+  /* Streams that do NOT synchronise with the null stream: the virtual-memory calls that add an
+   * arena block while a kernel runs wait for every stream the null stream waits for -- with
+   * blocking streams the host would wait for the kernel that waits for the host (measured:
+   * waves stalled for seconds until their bound, tools/vmm_block_probe.cpp cases F and G).
+   * Nothing here relies on the null stream's implicit ordering: copies are either enqueued
+   * on these streams or synchronous and issued after hipStreamSynchronize. */
 #ifdef PSD_EMU
+  hipError_t e = hipStreamCreate(&s->stream);
   if (e == hipSuccess) e = hipStreamCreate(&s->stream2);
 #else
+  hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
   if (e == hipSuccess) {
     /* the latency-build part of a mixed launch must get its CUs before the packed part does */
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    e = hipStreamCreateWithPriority(&s->stream2, hipStreamDefault, hi);
+    e = hipStreamCreateWithPriority(&s->stream2, hipStreamNonBlocking, hi);
   }
 #endif
   if (e == hipSuccess) e = hipEventCreate(&s->ev2);
@@ -998,6 +1102,59 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
   return 0;
 }
 
+namespace {
+/* While the kernels of a solve run: a second host thread maps arena blocks AHEAD of what the
+ * waves have taken (ar_used, a pinned word the waves add to whenever they take chunks), up to
+ * what the device and PEAKSEG_HIP_MAX_BYTES allow.  A wave that needs a block that is not there
+ * yet waits for it (arena_take); when no more can come the thread says so and the wave parks its
+ * problem.  Mapping a block is 13-35 ms per GB where the memory has been used before: at the
+ * 1.3 GB/s the 64-penalty grid stores, or the 14 GB/s of a full chip, the thread keeps ahead. */
+struct LiveGrower {
+  psd_problem_set *s = nullptr;
+  unsigned long long limit = 0; /* pieces the arena may reach */
+  std::atomic<bool> stop{false};
+  std::thread th;
+  unsigned long long added = 0;
+
+  void start(psd_problem_set *set, unsigned long long limit_pieces) {
+    s = set;
+    limit = limit_pieces;
+    __atomic_store_n(&s->h_live[0], arena_mapped(s), __ATOMIC_RELAXED);
+    __atomic_store_n(&s->h_live[1], 0ull, __ATOMIC_RELEASE);
+    th = std::thread([this]() { run(); });
+  }
+  void run() {
+    (void)hipSetDevice(s->device);
+    const unsigned long long B = 1ull << s->d.ar_block_log2;
+    bool final = false;
+    while (!stop.load(std::memory_order_acquire)) {
+      bool progressed = false;
+      for (;;) {
+        const unsigned long long used = __atomic_load_n(s->h_used, __ATOMIC_ACQUIRE);
+        unsigned long long ahead = used / 8ull;
+        if (ahead < 2ull * B) ahead = 2ull * B;
+        if (final || arena_mapped(s) >= used + ahead) break;
+        if (arena_mapped(s) + B > limit || arena_add_block(s) != 0) {
+          final = true; /* the capacity published so far is all there will be */
+          __atomic_store_n(&s->h_live[1], 1ull, __ATOMIC_RELEASE);
+          break;
+        }
+        added++;
+        progressed = true;
+      }
+      if (!progressed) std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+  }
+  void finish() {
+    if (!th.joinable()) return;
+    stop.store(true, std::memory_order_release);
+    th.join();
+    __atomic_store_n(&s->h_live[1], 1ull, __ATOMIC_RELEASE);
+  }
+  ~LiveGrower() { finish(); }
+};
+}  // namespace
+
 /* what the mixed-launch planner assumes a problem advances at, refreshed by every solve that
  * ran on one build alone with every problem resident from the start (a clean measurement) */
 static std::atomic<double> g_lat_rate{90e3}, g_thr_rate{27e3};
@@ -1005,6 +1162,7 @@ static std::atomic<double> g_lat_rate{90e3}, g_thr_rate{27e3};
 extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_ms,
                                              float *backtrack_ms) {
   HIP_TRY(hipSetDevice(s->device));
+  g_last_warning.clear();
   /* the latency build wants a CU per problem: beyond that, problems would queue behind each
    * other and the throughput build (4 per CU) finishes the set sooner.
    * PEAKSEG_HIP_VARIANT=lat|thr overrides (tests, A/B runs). */
@@ -1060,18 +1218,32 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
   std::fill(s->resume_t.begin(), s->resume_t.end(), 0);
   if (s->can_park) HIP_TRY(hipMemsetAsync(s->d_resume, 0, sizeof(int) * (size_t)s->n_problems, s->stream));
   HIP_TRY(hipMemsetAsync(s->d.ar_next_chunk, 0, sizeof(unsigned long long), s->stream));
+  __atomic_store_n(s->h_used, 0ull, __ATOMIC_RELEASE); /* follows ar_next_chunk */
   s->launches = 0;
   s->steps_run = 0;
+  s->live_blocks_added = 0;
+  s->pack_total = -1;
+  s->parks = 0;
+  s->park_pool_pieces = 0;
   float total_ms = 0.f;
   for (int attempt = 0;; attempt++) {
-    if (s->ckpt_interval > 0 &&
-        s->d.ar_cap < s->d.ckpt_region * 2ull * (unsigned long long)s->n_problems) {
-      set_error("checkpointed store: arena of %llu pieces is smaller than its %d regions of %llu",
-                s->d.ar_cap, 2 * s->n_problems, s->d.ckpt_region);
-      return ERROR_DEVICE_MEMORY;
+    if (s->ckpt_interval > 0) {
+      const unsigned long long B = 1ull << s->d.ar_block_log2;
+      const unsigned long long per_block = s->d.ckpt_region ? B / s->d.ckpt_region : 0ull;
+      const unsigned long long n_regions = 2ull * (unsigned long long)s->n_problems;
+      if (per_block == 0 || s->arena_blocks.size() < (n_regions + per_block - 1) / per_block) {
+        set_error("checkpointed store: arena of %llu pieces is smaller than its %d regions of %llu",
+                  s->d.ar_cap, 2 * s->n_problems, s->d.ckpt_region);
+        return ERROR_DEVICE_MEMORY;
+      }
     }
     const int n_todo = (int)todo.size();
     const bool relaunch = attempt > 0;
+    /* the arena may grow under this launch's kernels */
+    LiveGrower grower;
+    const bool live = s->live_growth && s->ckpt_interval == 0 && s->arena_auto;
+    s->d.ar_live = live ? s->h_live : nullptr;
+    s->d.ar_used = s->h_used;
     psd::DeviceArgs d_run = s->d;
     if (relaunch) {
       /* only the unfinished problems, in their original order */
@@ -1086,11 +1258,18 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
     if (s->ckpt_interval > 0)
       HIP_TRY(hipMemsetAsync(s->d.ar_next_chunk, 0, sizeof(unsigned long long), s->stream));
     HIP_TRY(hipMemsetAsync(s->d.spill_next, 0, sizeof(int), s->stream));
-    if (s->d.ckpt_ovf_next)
+    /* Overflow pool.  Checkpointed store: every relaunched problem starts over and saves its
+     * checkpoints again, so the pool starts empty.  Full store: the pool holds the functions of
+     * PARKED problems (those longer than a park slot) from the launch that parked them until the
+     * workgroup that resumes them has read them back -- which, in a grid larger than the chip
+     * holds resident, can be long after other workgroups of the same launch have parked again:
+     * the pool is emptied once per solve, never between its launches. */
+    if (s->d.ckpt_ovf_next && (s->ckpt_interval > 0 || !relaunch))
       HIP_TRY(hipMemsetAsync(s->d.ckpt_ovf_next, 0, sizeof(unsigned long long), s->stream));
     HIP_TRY(hipMemcpyAsync(const_cast<psd::DeviceArgs *>(s->d.self), &d_run, sizeof(psd::DeviceArgs),
                            hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipEventRecord(s->ev[0], s->stream));
+    if (live) grower.start(s, arena_mapped(s) + arena_fit(s));
     const dim3 grid((unsigned)n_todo);
     const bool thr_now = relaunch ? (forced ? s->throughput : n_todo > s->n_cu) : s->throughput;
     if (!relaunch && s->throughput && s->n_lat_mixed > 0) {
@@ -1123,8 +1302,9 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
           std::this_thread::yield();
         if (__atomic_load_n(s->started, __ATOMIC_ACQUIRE) < L) {
           s->mixed_wait_timed_out = true;
-          set_error("mixed launch: %d of %d latency-build workgroups had not started after 0.5 s; "
-                    "the packed part was launched anyway", L - *s->started, L);
+          set_warning("mixed launch: %d of %d latency-build workgroups had not started after 0.5 s; "
+                      "the packed part was launched anyway",
+                      L - __atomic_load_n(s->started, __ATOMIC_ACQUIRE), L);
         }
       }
       if (s->ckpt_interval > 0)
@@ -1153,7 +1333,14 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[1], s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    {
+      const hipError_t e_sync = hipStreamSynchronize(s->stream);
+      grower.finish(); /* (before any return: the thread works on *s) */
+      s->live_blocks_added += grower.added;
+      HIP_TRY(e_sync);
+      int st_tab = arena_sync_table(s);
+      if (st_tab) return st_tab;
+    }
     float f_ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&f_ms, s->ev[0], s->ev[1]));
     total_ms += f_ms;
@@ -1180,22 +1367,32 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
       s->arena_used = chunks << s->d.ar_chunk_log2;
       if (s->arena_used > s->d.ar_cap) s->arena_used = s->d.ar_cap;
     }
-    bool arena_full = false, spill_full = false, ckpt_full = false;
+    bool arena_full = false, spill_full = false, ckpt_full = false, park_pool_full = false;
     int longest_function = 0;
     std::vector<int> again;
     for (int p : todo) {
       const psd::ProbResult &r = s->results[(size_t)p];
       arena_full = arena_full || r.status == psd::PST_ARENA_FULL;
+      /* out of arena beyond data point 0 and not parked although the set has park slots: its
+       * functions were too long for a slot and the overflow pool had no room for them */
+      park_pool_full = park_pool_full || (r.status == psd::PST_ARENA_FULL && s->can_park &&
+                                          !r.parked && r.step_reached > 0);
       spill_full = spill_full || r.status == psd::PST_SPILL_FULL;
       ckpt_full = ckpt_full || r.status == psd::PST_CKPT_FULL;
       if (r.max_intervals > longest_function) longest_function = r.max_intervals;
       if (r.status == psd::PST_ARENA_FULL || r.status == psd::PST_SPILL_FULL ||
           r.status == psd::PST_CKPT_FULL) {
         again.push_back(p);
+        if (r.status == psd::PST_ARENA_FULL && r.parked && s->can_park) s->parks++;
         /* parked: go on where it stopped; anything else starts over */
         s->resume_t[(size_t)p] =
             (r.status == psd::PST_ARENA_FULL && r.parked && s->can_park) ? r.step_reached : 0;
       }
+    }
+    if (s->ckpt_interval == 0 && s->d.ckpt_ovf_next) { /* the parks' share of the overflow pool */
+      unsigned long long used = 0;
+      HIP_TRY(hipMemcpy(&used, s->d.ckpt_ovf_next, sizeof used, hipMemcpyDeviceToHost));
+      s->park_pool_pieces = used;
     }
     if (again.empty()) break;
     if (getenv("PEAKSEG_HIP_TIMING")) {
@@ -1211,6 +1408,15 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
       set_error("cost-function arena (%llu pieces) / spill pool (%d slots) still too small after "
                 "%d relaunches", s->arena_pieces, s->spill_slots, attempt);
       return ERROR_DEVICE_MEMORY;
+    }
+    if (park_pool_full && s->ckpt_interval == 0) {
+      /* such problems start over this time; with four times the pool (what other parked
+       * problems keep in it is preserved) the next exhaustion parks them */
+      const unsigned long long bigger = s->d.ckpt_ovf_cap * 4ull;
+      if (bigger <= arena_fit(s) * 20ull / 52ull) {
+        int st = grow_ckpt_overflow_keep(s, bigger);
+        if (st) return st;
+      }
     }
     if (ckpt_full) {
       unsigned long long bigger = s->d.ckpt_ovf_cap * 4ull;
@@ -1246,7 +1452,6 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
          * that length always fit then) when that is more.  The regions are scratch for the
          * decoding's recomputation: re-allocated, never kept. */
         const unsigned long long old_ppf = s->ckpt_pieces_per_fn;
-        const unsigned long long old_pieces = s->arena_pieces;
         s->ckpt_pieces_per_fn *= 2ull;
         if (s->ckpt_pieces_per_fn < (unsigned long long)longest_function)
           s->ckpt_pieces_per_fn = (unsigned long long)longest_function;
@@ -1254,39 +1459,37 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
         const unsigned long long bigger = s->d.ckpt_region * 2ull * (unsigned long long)s->n_problems;
         free_arena(s);
         const unsigned long long fit = arena_fit(s);
-        if (bigger > fit) {
-          /* The kernel indexes region (2 p + chain) of ckpt_region pieces without looking at
-           * ar_cap: an arena clipped to what fits would be written beyond its end.  No clipping
-           * here: the regions either fit or the set does not. */
-          set_error("checkpointed store: %llu pieces per region x %d regions (%llu bytes) do not "
-                    "fit (free HBM / PEAKSEG_HIP_MAX_BYTES)", s->d.ckpt_region, 2 * s->n_problems,
-                    bigger * 20ull);
+        int st = alloc_arena(s, bigger, fit); /* (refuses, never clips, what does not fit) */
+        if (st) {
+          const std::string why = g_last_error;
           s->ckpt_pieces_per_fn = old_ppf;
           s->d.ckpt_region = (unsigned long long)(s->ckpt_interval + 1) * s->ckpt_pieces_per_fn;
-          (void)alloc_arena(s, old_pieces < fit ? old_pieces : fit);
-          return ERROR_DEVICE_MEMORY;
+          if (s->arena_blocks.empty() && s->d.ar_block == nullptr)
+            (void)alloc_arena(s, s->d.ckpt_region * 2ull * (unsigned long long)s->n_problems, fit);
+          g_last_error = why;
+          return st;
         }
-        int st = alloc_arena(s, bigger);
-        if (st) return st;
       } else {
-        /* Full store: the arena GROWS in place.  How much more: what the unfinished problems' progress
-         * says the rest of the set needs (pieces handed out so far x data points left / data
-         * points done, x 1.3); at least a quarter of what the arena has where it grows by
-         * mapping, as much again where it grows by copying. */
-        double done = 0.0, all = 0.0;
+        /* Full store: the arena GROWS by whole blocks (problems come here parked when the live
+         * growth could not keep up or was switched off).  How much more: what the unfinished
+         * problems' progress says the rest of the set needs (pieces handed out so far x data
+         * points left / data points done, x 1.3); at least a quarter of what the arena has. */
+        /* (a problem that could not be parked starts over and stores all its records again;
+         * those of its first attempt stay where they are, unused) */
+        double done = 0.0, rest = 0.0;
         for (int p = 0; p < s->n_problems; p++) {
           const double n = (double)s->contig_n[(size_t)s->prob_contig[(size_t)p]];
           const psd::ProbResult &r = s->results[(size_t)p];
-          all += n;
           done += r.status == 0 ? n : (double)r.step_reached;
+          if (r.status != 0) rest += n - (double)s->resume_t[(size_t)p];
         }
-        unsigned long long more = s->arena_vmm ? s->arena_pieces / 4ull : s->arena_pieces;
+        unsigned long long more = s->arena_pieces / 4ull;
         if (done > 0.0) {
-          const double need = (double)s->arena_pieces * ((all - done) / done) * 1.3;
+          const double left = (double)(s->d.ar_cap - s->arena_used);
+          const double need = (double)s->arena_used / done * rest * 1.3 - left;
           if (need > (double)more) more = (unsigned long long)need;
         }
-        unsigned long long fit = arena_fit(s);
-        if (!s->arena_vmm) fit /= 2ull; /* growing by copy holds the old and the new arrays at once */
+        const unsigned long long fit = arena_fit(s);
         if (more > fit) more = fit;
         const unsigned long long chunk = 1ull << s->d.ar_chunk_log2;
         if (more < chunk * 4ull * (unsigned long long)again.size()) {
@@ -1294,7 +1497,7 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
                     "PEAKSEG_HIP_MAX_BYTES)", s->arena_pieces);
           return ERROR_DEVICE_MEMORY;
         }
-        int st = alloc_arena(s, s->arena_pieces + more);
+        int st = alloc_arena(s, s->arena_pieces + more, s->arena_pieces + fit);
         if (st) return st;
       }
     }
@@ -1399,9 +1602,14 @@ extern "C" int peakseg_hip_problem_set_export_db(psd_problem_set *s, int p, cons
       mx.resize((size_t)n);
       prv.resize((size_t)n);
       di.resize((size_t)n);
-      if (hipMemcpy(mx.data(), s->d.ar_mx + off, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-          hipMemcpy(prv.data(), s->d.ar_prv + off, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-          hipMemcpy(di.data(), s->d.ar_di + off, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+      /* the record's block and its three arrays (fpop_types.h) */
+      const int blg = s->d.ar_block_log2;
+      const size_t blk = (size_t)(off >> blg), w = (size_t)(off & ((1ull << blg) - 1ull));
+      const char *bb = blk < s->arena_blocks.size() ? (const char *)s->arena_blocks[blk].base : nullptr;
+      if (!bb ||
+          hipMemcpy(mx.data(), bb + w * 8, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(prv.data(), bb + ((size_t)8 << blg) + w * 8, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(di.data(), bb + ((size_t)16 << blg) + w * 4, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) {
         fclose(f);
         return -1;
       }
@@ -1494,6 +1702,109 @@ extern "C" int peakseg_hip_math_probe(int op, int n, const double *x, double *y)
   (void)hipFree(dx);
   (void)hipFree(dy);
   return 0;
+}
+
+/* ---- segment tables packed in HBM (the multi-GPU gather's payload) ----------------------- */
+
+/* one workgroup per problem: rows[3 p] = first packed row, rows[3 p + 1] = row count,
+ * rows[3 p + 2] = the table's offset in seg_start / seg_mean */
+__global__ void pack_tables_kernel(const int *seg_start, const double *seg_mean,
+                                   const long long *rows, int *out_start, double *out_mean) {
+  const long long to = rows[3 * blockIdx.x], n = rows[3 * blockIdx.x + 1],
+                  from = rows[3 * blockIdx.x + 2];
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+    out_start[to + i] = seg_start[from + i];
+    out_mean[to + i] = seg_mean[from + i];
+  }
+}
+
+extern "C" long long peakseg_hip_problem_set_pack_tables(psd_problem_set *s, long long *rows_out,
+                                                         const int **start_dev,
+                                                         const double **mean_dev) {
+  if (!s || !s->solved) return -1;
+  if (hipSetDevice(s->device) != hipSuccess) return -1;
+  std::vector<long long> rows((size_t)3 * (size_t)s->n_problems);
+  long long total = 0;
+  for (int p = 0; p < s->n_problems; p++) {
+    const psd::ProbResult &r = s->results[(size_t)p];
+    const long long n = r.status == 0 ? r.n_segments : 0;
+    rows[(size_t)3 * p] = total;
+    rows[(size_t)3 * p + 1] = n;
+    rows[(size_t)3 * p + 2] = s->prob_seg_off[(size_t)p];
+    if (rows_out) rows_out[p] = n;
+    total += n;
+  }
+  if (total > s->pack_capacity || !s->d_pack_rows) {
+    for (void *q : {(void *)s->d_pack_start, (void *)s->d_pack_mean}) {
+      if (!q) continue;
+      forget_alloc(s, q);
+      (void)hipFree(q);
+    }
+    s->bytes -= (unsigned long long)s->pack_capacity * 12ull;
+    s->d_pack_start = nullptr;
+    s->d_pack_mean = nullptr;
+    s->pack_capacity = 0;
+    if (dev_alloc(s, &s->d_pack_start, (size_t)total) || dev_alloc(s, &s->d_pack_mean, (size_t)total))
+      return -1;
+    s->pack_capacity = total > 0 ? total : 1;
+    if (!s->d_pack_rows && dev_alloc(s, &s->d_pack_rows, rows.size())) return -1;
+  }
+  if (hipMemcpy(s->d_pack_rows, rows.data(), rows.size() * sizeof(long long),
+                hipMemcpyHostToDevice) != hipSuccess)
+    return -1;
+  hipLaunchKernelGGL(pack_tables_kernel, dim3((unsigned)s->n_problems), dim3(256), 0, s->stream,
+                     (const int *)s->d.seg_start, (const double *)s->d.seg_mean,
+                     (const long long *)s->d_pack_rows, s->d_pack_start, s->d_pack_mean);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) {
+    set_error("packing the segment tables failed");
+    return -1;
+  }
+  s->pack_total = total;
+  if (start_dev) *start_dev = s->d_pack_start;
+  if (mean_dev) *mean_dev = s->d_pack_mean;
+  return total;
+}
+
+extern "C" int peakseg_hip_problem_set_packed_download(psd_problem_set *s, int *start_out,
+                                                       double *mean_out) {
+  if (!s || s->pack_total < 0) return -1;
+  const size_t n = (size_t)s->pack_total;
+  if (n == 0) return 0;
+  if (hipMemcpy(start_out, s->d_pack_start, n * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(mean_out, s->d_pack_mean, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+    set_error("download of the packed segment tables failed");
+    return -1;
+  }
+  return 0;
+}
+
+extern "C" int peakseg_hip_problem_set_park_stats(psd_problem_set *s, int *parks,
+                                                  unsigned long long *overflow_pool_pieces) {
+  if (!s) return -1;
+  if (parks) *parks = s->parks;
+  if (overflow_pool_pieces) *overflow_pool_pieces = s->park_pool_pieces;
+  return 0;
+}
+
+/* shader cycles the problem's workgroup ran in the last launch that touched it */
+extern "C" long long peakseg_hip_problem_set_cycles(psd_problem_set *s, int p) {
+  if (!s || !s->solved || p < 0 || p >= s->n_problems) return -1;
+  return s->results[(size_t)p].cycles;
+}
+
+/* data points per second one problem advanced at in this process's last clean single-build
+ * solves (what the mixed-launch planner reasons with); the defaults before any */
+extern "C" void peakseg_hip_measured_rates(double *lat_rate, double *thr_rate) {
+  if (lat_rate) *lat_rate = g_lat_rate.load();
+  if (thr_rate) *thr_rate = g_thr_rate.load();
+}
+
+/* the bound on the polls of a wait between waves (tests/test_gpu_round4.py) and, in builds with
+ * -DPSD_SPIN_STATS, the largest poll count a problem's waves saw */
+extern "C" long long peakseg_hip_spin_limit(void) { return (long long)psd::lat::WAIT_SPIN_LIMIT; }
+extern "C" int peakseg_hip_problem_set_max_spin(psd_problem_set *s, int p) {
+  if (!s || !s->solved || p < 0 || p >= s->n_problems) return -1;
+  return s->results[(size_t)p].max_spin;
 }
 
 /* ---- file-level solver (the reference's boundary), directory-level batch with the cache

@@ -136,6 +136,35 @@ PSD_D void spin_pause() { __builtin_amdgcn_s_sleep(1); }
 PSD_D void device_fence() { __threadfence(); }
 #endif
 
+/* words shared with the host while a kernel runs (pinned host memory): system scope.  Only
+ * loads and fetch-add: PCIe atomics know no max. */
+#ifdef PSD_EMU
+PSD_D unsigned long long sys_load_u64(const unsigned long long *p) {
+  return __atomic_load_n(p, __ATOMIC_ACQUIRE);
+}
+PSD_D void sys_add_u64(unsigned long long *p, unsigned long long v) {
+  (void)__atomic_fetch_add(p, v, __ATOMIC_RELEASE);
+}
+/* an entry of a device table that other waves of the launch fill in */
+PSD_D char *agent_load_ptr(char *const *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+PSD_D void agent_store_ptr(char **p, char *v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+#else
+PSD_D unsigned long long sys_load_u64(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+PSD_D void sys_add_u64(unsigned long long *p, unsigned long long v) {
+  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+PSD_D char *agent_load_ptr(char *const *p) {
+  return (char *)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+}
+PSD_D void agent_store_ptr(char **p, char *v) {
+  __hip_atomic_store((unsigned long long *)p, (unsigned long long)v, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+
 template <class T>
 PSD_D T *uniform_p(T *p) {
 #ifdef PSD_EMU

@@ -93,6 +93,56 @@ class ProblemSet:
         self._lib.peakseg_hip_problem_set_solve_stats(self._h, ctypes.byref(n), ctypes.byref(steps))
         return n.value, steps.value
 
+    @property
+    def arena_stats(self):
+        """(pieces per arena block, blocks mapped now, blocks the last solve() mapped while its
+        kernels were running)"""
+        bp = ctypes.c_ulonglong()
+        nb = ctypes.c_int()
+        live = ctypes.c_int()
+        self._lib.peakseg_hip_problem_set_arena_stats(self._h, ctypes.byref(bp), ctypes.byref(nb),
+                                                      ctypes.byref(live))
+        return bp.value, nb.value, live.value
+
+    @property
+    def park_stats(self):
+        """(problems parked by the last solve()'s launches, pieces of the overflow pool those
+        parks took)"""
+        n = ctypes.c_int()
+        pool = ctypes.c_ulonglong()
+        self._lib.peakseg_hip_problem_set_park_stats(self._h, ctypes.byref(n), ctypes.byref(pool))
+        return n.value, pool.value
+
+    def pack_tables(self):
+        """Pack every problem's segment table at its exact size in HBM.  Returns (rows int64[k],
+        device address of the packed seg_start int32 array, of the packed seg_mean float64
+        array, total rows); the addresses stay valid until the next solve() / close()."""
+        rows = np.zeros(len(self.problems), dtype=np.int64)
+        ps = ctypes.c_void_p()
+        pm = ctypes.c_void_p()
+        total = self._lib.peakseg_hip_problem_set_pack_tables(
+            self._h, rows.ctypes.data, ctypes.byref(ps), ctypes.byref(pm))
+        if total < 0:
+            raise RuntimeError("pack_tables: %s" % self._lib.peakseg_hip_last_error().decode())
+        return rows, ps.value or 0, pm.value or 0, int(total)
+
+    def packed_download(self, total):
+        """the packed tables of pack_tables() as host arrays"""
+        start = np.empty(total, dtype=np.int32)
+        mean = np.empty(total, dtype=np.float64)
+        if self._lib.peakseg_hip_problem_set_packed_download(self._h, start.ctypes.data,
+                                                             mean.ctypes.data) != 0:
+            raise RuntimeError("packed_download: %s" % self._lib.peakseg_hip_last_error().decode())
+        return start, mean
+
+    def cycles_per_step(self, p):
+        """shader cycles per data point of problem p in the last solve() (0.0 when unknown,
+        e.g. under the SIMT emulator, or when the problem was resumed after a park)"""
+        cyc = int(self._lib.peakseg_hip_problem_set_cycles(self._h, p))
+        if cyc <= 0 or self.solve_stats[0] != 1:
+            return 0.0
+        return cyc / float(len(self.contigs[self.problems[p][0]][0]))
+
     def set_penalty(self, p, penalty):
         """Change one problem's penalty in place; the next solve() reuses contig and arena."""
         if self._lib.peakseg_hip_problem_set_set_penalty(self._h, p, float(penalty)) != 0:

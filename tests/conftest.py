@@ -22,6 +22,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# The three GPU tests that take a minute or more run LAST, longest last: if a slow box runs the
+# driver's `pytest -x` into its time limit, the kill loses the fewest tests.
+_LONG_GPU_TESTS = ["test_endpoints_vs_glibc_arithmetic_1e6_x64", "test_sequential_search_on_a_long_contig",
+                   "test_endpoints_vs_glibc_arithmetic_1e7_x64"]
+
+
+def pytest_collection_modifyitems(config, items):
+    def rank(item):
+        name = item.name.split("[")[0]
+        return _LONG_GPU_TESTS.index(name) + 1 if name in _LONG_GPU_TESTS else 0
+    items.sort(key=rank)  # stable: everything else keeps its order
+
+
 @pytest.fixture(autouse=True)
 def _flush_c_stdio():
     """The oracle prints the reference's messages with printf: flush them into the test's own

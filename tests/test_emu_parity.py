@@ -14,6 +14,7 @@ import pytest
 import test_gpu_parity as gp
 import test_gpu_round2 as gp2
 import test_gpu_round3 as gp3
+import test_gpu_round4 as gp4
 from conftest import ROOT
 
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
@@ -150,31 +151,20 @@ def test_emu_varied_data_shapes(psd, oracle_det, tmp_path, monkeypatch):
 
 
 def test_emu_grid_properties_small(psd):
-    """The property checks of the full-size GPU test on a small grid (structure of the test
-    itself; the arithmetic is the same)."""
+    """The property checks of the full-size GPU test (test_gpu_parity.check_grid_properties) on
+    a small grid, and determinism of a second solve."""
     import numpy as np
     from peaksegdisk_amd import ProblemSet, synthetic
     cs, ce, cnt = synthetic.poisson_coverage(3000, seed=1)
-    w = (ce - cs).astype(np.int32)
     pens = synthetic.penalty_grid(6)
-    pset = ProblemSet([(cnt, w)], [(0, float(p)) for p in pens])
+    pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, float(p)) for p in pens])
     pset.solve()
-    cw = np.concatenate([[0.0], np.cumsum(w.astype(np.float64))])
-    cz = np.concatenate([[0.0], np.cumsum(w.astype(np.float64) * cnt)])
-    peaks = []
-    for i, pen in enumerate(pens):
-        r = pset.result(i)
+    first = gp.check_grid_properties(pset, pens, cs, ce, cnt, 3000)
+    pset.solve()
+    for i in range(len(pens)):
         start, mean = pset.segments(i)
-        lo = start[::-1] + 1
-        hi = np.concatenate([lo[1:], [3000]])
-        m = mean[::-1]
-        assert (m[1::2] >= m[0:-1:2]).all() and (m[1::2] >= m[2::2]).all()
-        seg_w, seg_z = cw[hi] - cw[lo], cz[hi] - cz[lo]
-        with np.errstate(divide="ignore", invalid="ignore"):
-            loss = np.where(seg_z > 0, seg_w * m - seg_z * np.log(m), seg_w * m).sum()
-        assert r.best_cost * cw[-1] - float(pen) * r.n_peaks == pytest.approx(loss, rel=1e-6)
-        peaks.append(r.n_peaks)
-    assert all(a >= b for a, b in zip(peaks, peaks[1:]))
+        assert np.array_equal(start, first[i][0])
+        assert np.array_equal(mean.view(np.uint64), first[i][1].view(np.uint64))
     pset.close()
 
 
@@ -250,3 +240,27 @@ def test_emu_arena_regrowth_resumes(psd, oracle_det, tmp_path, monkeypatch):
 
 def test_emu_checkpointed_store_large_penalties(psd, monkeypatch):
     gp3.test_checkpointed_store_large_penalties_single_launch(psd, monkeypatch, n_bins=1500)
+
+
+def test_emu_arena_grows_while_the_kernel_runs(psd, oracle_det, tmp_path, monkeypatch):
+    # (the emulator runs the kernel on the calling thread; the thread that adds blocks is real)
+    gp3.test_arena_grows_while_the_kernel_runs(psd, oracle_det, tmp_path, monkeypatch, n_bins=1500,
+                                               block_log2="12")
+
+
+def test_emu_search_for_most_peaks_minus_one(psd, tmp_path, monkeypatch):
+    from peaksegdisk_amd import synthetic
+    monkeypatch.setenv("PEAKSEG_HIP_VARIANT", "thr")  # host-side logic, as above
+    cs, ce, cnt = synthetic.poisson_coverage(700, seed=41)
+    text = "".join("chrSynth\t%d\t%d\t%d\n" % t for t in zip(cs.tolist(), ce.tolist(), cnt.tolist()))
+    gp4.test_search_for_most_peaks_minus_one(psd, tmp_path, text=text, most_peaks=None)
+
+
+def test_emu_search_with_too_many_peaks_on_six_points(psd, tmp_path):
+    gp4.test_search_with_too_many_peaks_on_six_points(psd, tmp_path)
+
+
+def test_emu_parked_long_functions_survive_several_exhaustions(psd, oracle_det, tmp_path,
+                                                               monkeypatch):
+    gp4.test_parked_long_functions_survive_several_exhaustions(psd, oracle_det, tmp_path,
+                                                               monkeypatch, n_bins=1200)

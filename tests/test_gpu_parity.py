@@ -313,13 +313,9 @@ def _shaped_counts(kind, n, rng):
     return np.asarray(cnt).astype(np.int32)
 
 
-@GPU
-@pytest.mark.parametrize("n_cases,seed", [(18, 2024)])
-def test_varied_data_shapes(psd, oracle_det, tmp_path, monkeypatch, n_cases, seed):
-    """Coverage that does not look like the Poisson generator: heavy tails, long zero runs,
-    counts in the millions, smooth ramps, steps, 0/1 data, random bin widths and penalties
-    (0 included).  Both kernel builds; every stored function against the oracle's db."""
-    from peaksegdisk_amd import ProblemSet, synthetic
+def varied_shape_cases(n_cases, seed):
+    """(count, width, chromStart, chromEnd, penalty strings) of the data shapes below; also
+    solved by both oracle builds in tests/test_oracle_census.py"""
     rng = np.random.default_rng(seed)
     for case in range(n_cases):
         n = int(rng.integers(500, 4000))
@@ -329,6 +325,20 @@ def test_varied_data_shapes(psd, oracle_det, tmp_path, monkeypatch, n_cases, see
         cs = ce - w
         pens = ["0", "%.15g" % float(10 ** rng.uniform(-2, 6)),
                 "%.15g" % float(10 ** rng.uniform(0, 4))]
+        yield cnt, w, cs, ce, pens
+
+
+VARIED_SHAPES_RUN = (18, 2024)
+
+
+@GPU
+@pytest.mark.parametrize("n_cases,seed", [VARIED_SHAPES_RUN])
+def test_varied_data_shapes(psd, oracle_det, tmp_path, monkeypatch, n_cases, seed):
+    """Coverage that does not look like the Poisson generator: heavy tails, long zero runs,
+    counts in the millions, smooth ramps, steps, 0/1 data, random bin widths and penalties
+    (0 included).  Both kernel builds; every stored function against the oracle's db."""
+    from peaksegdisk_amd import ProblemSet, synthetic
+    for case, (cnt, w, cs, ce, pens) in enumerate(varied_shape_cases(n_cases, seed)):
         bg = str(tmp_path / ("c%d.bedGraph" % case))
         synthetic.write_bedgraph(bg, cs, ce, cnt)
         want = []
@@ -395,29 +405,21 @@ def test_sequential_envelope_replay(psd, oracle_det, tmp_path):
         pset.close()
 
 
-@GPU
-def test_full_size_grid_properties(psd, oracle_det, tmp_path):
-    """BASELINE.json configs[1] at full size (1e6 bins x 64 penalties): properties that do not
-    need the oracle at that size, plus two penalties checked against the oracle outright.
+def check_grid_properties(pset, pens, cs, ce, cnt, n_bins):
+    """Size-independent properties of a solved (one contig x penalties) grid -- what the
+    full-size tests check where the oracle cannot follow:
       * every problem solves; segment tables are well formed (odd row count, strictly
         decreasing starts, last row = first_chromStart);
       * up/down constraint: means rise into every peak and fall out of it;
       * the reported total loss equals the Poisson loss recomputed from the segmentation
         (sum over segments of w*m - z*log m) to 1e-6 relative -- a checksum of the whole
         forward pass and backtrack;
-      * the number of peaks does not increase with the penalty;
-      * solving again gives bit-identical results (determinism)."""
-    from peaksegdisk_amd import ProblemSet, synthetic
-    n_bins = 1000000
-    cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=1)
-    w = (ce - cs).astype(np.int32)
-    pens = synthetic.penalty_grid(64)
-    pset = ProblemSet([(cnt, w)], [(0, float(p)) for p in pens])
-    pset.solve()
-    cw = np.concatenate([[0.0], np.cumsum(w.astype(np.float64))])
-    cz = np.concatenate([[0.0], np.cumsum(w.astype(np.float64) * cnt)])
-    peaks = []
-    first = []
+      * the number of peaks does not increase with the penalty.
+    Returns per problem (seg_start, seg_mean, best_cost) for a determinism check."""
+    w = (ce - cs).astype(np.float64)
+    cw = np.concatenate([[0.0], np.cumsum(w)])
+    cz = np.concatenate([[0.0], np.cumsum(w * cnt)])
+    peaks, first = [], []
     for i, pen in enumerate(pens):
         r = pset.result(i)
         assert r.status == 0, (pen, r.kernel_status)
@@ -440,30 +442,7 @@ def test_full_size_grid_properties(psd, oracle_det, tmp_path):
         assert total == pytest.approx(loss, rel=1e-6, abs=1e-6), pen
         peaks.append(r.n_peaks)
     assert all(a >= b for a, b in zip(peaks, peaks[1:])), peaks
-    assert peaks[0] > 1000 * peaks[-1] > 0
-    # determinism
-    pset.solve()
-    for i in (0, 31, 63):
-        start, mean = pset.segments(i)
-        assert np.array_equal(start, first[i][0])
-        assert np.array_equal(mean.view(np.uint64), first[i][1].view(np.uint64))
-        assert pset.result(i).best_cost == first[i][2]
-    # two penalties against the oracle at full size
-    bg = str(tmp_path / "coverage.bedGraph")
-    synthetic.write_bedgraph(bg, cs, ce, cnt)
-    for i in (20, 50):
-        assert oracle_det.solve(bg, pens[i]) == 0
-        segs = read_segments("%s_penalty=%s_segments.bed" % (bg, pens[i]))
-        start, mean = pset.segments(i)
-        assert [s[1] for s in segs] == [int(cs[0]) if k < 0 else int(ce[k]) for k in start]
-        assert [s[4] for s in segs] == ["%g" % v for v in mean]
-        loss = read_loss("%s_penalty=%s_loss.tsv" % (bg, pens[i])).split("\t")
-        r = pset.result(i)
-        assert loss[5] == "%.20g" % r.best_cost and float(loss[9]) == r.max_intervals
-        assert int(loss[7]) == r.n_equality_constraints
-        assert float(loss[8]) == r.total_intervals / (2.0 * n_bins)
-        os.unlink("%s_penalty=%s.db" % (bg, pens[i]))
-    pset.close()
+    return first
 
 
 # PSD_FUZZ_EXTRA="4000:11,4000:12": more (cases, seed) runs of the fuzz test, for soak runs on a
@@ -472,16 +451,10 @@ _FUZZ_RUNS = [(300, 5)] + [tuple(int(v) for v in item.split(":"))
                            for item in os.environ.get("PSD_FUZZ_EXTRA", "").split(",") if item]
 
 
-@GPU
-@pytest.mark.parametrize("n_cases,seed", _FUZZ_RUNS)
-def test_fuzz_tiny_problems(psd, oracle_det, tmp_path, n_cases, seed):
-    """Many tiny random problems in one problem set (ragged lengths 1..40, zeros, repeated
-    counts, increasing/decreasing runs, wide count ranges, penalties from 0 to 1e6): the rare
-    branches of the piece algebra (degenerate linear pieces, equal-at-left/right, crossings at
-    interval ends) against the oracle, problem by problem."""
-    from peaksegdisk_amd import ProblemSet
+def fuzz_cases(n_cases, seed):
+    """(count, width, chromStart, chromEnd, penalty string) of the tiny problems below; also
+    solved by both oracle builds in tests/test_oracle_census.py"""
     rng = np.random.default_rng(seed)
-    contigs, problems, texts, pens = [], [], [], []
     for c in range(n_cases):
         n = int(rng.integers(2, 41))
         kind = int(rng.integers(0, 5))
@@ -501,6 +474,19 @@ def test_fuzz_tiny_problems(psd, oracle_det, tmp_path, n_cases, seed):
         end = np.cumsum(wid)
         start = end - wid
         pen = "0" if rng.random() < 0.15 else "%.15g" % (10.0 ** rng.uniform(-2, 6))
+        yield cnt, wid, start, end, pen
+
+
+@GPU
+@pytest.mark.parametrize("n_cases,seed", _FUZZ_RUNS)
+def test_fuzz_tiny_problems(psd, oracle_det, tmp_path, n_cases, seed):
+    """Many tiny random problems in one problem set (ragged lengths 1..40, zeros, repeated
+    counts, increasing/decreasing runs, wide count ranges, penalties from 0 to 1e6): the rare
+    branches of the piece algebra (degenerate linear pieces, equal-at-left/right, crossings at
+    interval ends) against the oracle, problem by problem."""
+    from peaksegdisk_amd import ProblemSet
+    contigs, problems, texts, pens = [], [], [], []
+    for c, (cnt, wid, start, end, pen) in enumerate(fuzz_cases(n_cases, seed)):
         contigs.append((cnt.astype(np.int32), wid.astype(np.int32)))
         problems.append((c, float(pen)))
         pens.append(pen)

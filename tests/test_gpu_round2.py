@@ -92,8 +92,13 @@ def check_against_libm_files(pset, i, pen, bg, cs, ce, n_bins):
 def test_endpoints_vs_glibc_arithmetic_1e6_x64(psd, tmp_path):
     """BASELINE.json configs[1] at full size against the arithmetic the reference itself
     uses: ALL 64 penalties solved by oracle_cli_libm in a process pool while the GPU solves the
-    grid (round 2 sampled 17); every 8th penalty also by the deterministic build, to report how
-    many stored functions differ in piece count between the two arithmetics."""
+    grid (round 2 sampled 17); every 8th penalty also by the deterministic build -- whose files
+    the GPU's tables must equal exactly -- to report how many stored functions differ in piece
+    count between the two arithmetics.  On the same solve: the size-independent properties
+    (test_gpu_parity.check_grid_properties: well-formed tables, up/down constraint, the loss
+    recomputed from the segmentation, peaks monotone in the penalty) and determinism of a second
+    solve, which also has to find the arena the first one grew (round 4: one solve of this
+    grid per test run instead of two)."""
     from peaksegdisk_amd import ProblemSet, synthetic
     n_bins = 1000000
     cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=1)
@@ -136,6 +141,28 @@ def test_endpoints_vs_glibc_arithmetic_1e6_x64(psd, tmp_path):
         report["penalties"][pens[i]]["functions_with_different_piece_count_det_vs_glibc"] = \
             int((a != b).sum())
         report["penalties"][pens[i]]["functions"] = int(2 * n_bins - 1)
+        # ... and the deterministic oracle's files exactly
+        segs = read_segments("%s_penalty=%s_segments.bed" % (dbg, pens[i]))
+        start, mean = pset.segments(i)
+        assert [s[1] for s in segs] == [int(cs[0]) if k < 0 else int(ce[k]) for k in start]
+        assert [s[4] for s in segs] == ["%g" % v for v in mean]
+        loss = read_loss("%s_penalty=%s_loss.tsv" % (dbg, pens[i])).split("\t")
+        assert loss[5] == "%.20g" % r.best_cost and float(loss[9]) == r.max_intervals
+        assert int(loss[7]) == r.n_equality_constraints
+        assert float(loss[8]) == r.total_intervals / (2.0 * n_bins)
+    # size-independent properties of all 64 problems, then determinism of a second solve
+    from test_gpu_parity import check_grid_properties
+    first = check_grid_properties(pset, pens, cs, ce, cnt, n_bins)
+    peaks = [pset.result(i).n_peaks for i in range(64)]
+    assert peaks[0] > 1000 * peaks[-1] > 0
+    report["arena_blocks_mapped_under_the_kernel"] = pset.arena_stats[2]
+    pset.solve()
+    assert pset.solve_stats[0] == 1 and pset.arena_stats[2] == 0
+    for i in (0, 31, 63):
+        start, mean = pset.segments(i)
+        assert np.array_equal(start, first[i][0])
+        assert np.array_equal(mean.view(np.uint64), first[i][1].view(np.uint64))
+        assert pset.result(i).best_cost == first[i][2]
     pset.close()
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
@@ -679,6 +706,9 @@ def test_checkpointed_store_region_regrowth_and_limits(psd, tmp_path, monkeypatc
     # (blocks of 2048 data points: the regions the decoding needs, 2049 functions of some 250
     # pieces per chain, are larger than the smallest arena the library maps)
     monkeypatch.setenv("PEAKSEG_HIP_CHECKPOINT", "2048" if adv_bins > 2500 else "256")
+    # (arena blocks of 4096 pieces instead of the usual 2^19 and more, so that the regrown
+    # regions need memory the first allocation did not already hold)
+    monkeypatch.setenv("PEAKSEG_HIP_ARENA_BLOCK_LOG2", "12")
     probe = ProblemSet([(c2, w2)], [(0, 100.0)])
     held = probe.hbm_bytes
     probe.close()
@@ -690,6 +720,7 @@ def test_checkpointed_store_region_regrowth_and_limits(psd, tmp_path, monkeypatc
     monkeypatch.delenv("PEAKSEG_HIP_MAX_BYTES")
     monkeypatch.delenv("PEAKSEG_HIP_PIECES_PER_FUNCTION")
     monkeypatch.delenv("PEAKSEG_HIP_CHECKPOINT")
+    monkeypatch.delenv("PEAKSEG_HIP_ARENA_BLOCK_LOG2")
     if not auto_bins:
         return
     # automatic choice under a cap: 200 k bins x 4 penalties need ~280 MB in full (estimate:

@@ -313,11 +313,38 @@ def test_sequential_search_on_a_long_contig(psd, tmp_path, n_bins=1000000, peaks
                 cs[o:o + 500000].tolist(), ce[o:o + 500000].tolist(), cnt[o:o + 500000].tolist())))
     os.link(bg, str(gdir / "coverage.bedGraph"))
     t0 = time.time()
-    fit = psd.sequentialSearch_dir(str(gdir), peaks_int)
+    # The oracle solves each model WHILE the search goes on (round 4: the driver's GPU test step
+    # had 290 s of oracle work on host cores behind the GPU's): the search leaves a model's
+    # _loss.tsv the moment that model is done, a watcher starts the oracle on that penalty at
+    # once, and when the search returns only the last model's oracle run is still outstanding.
+    gbg = str(gdir / "coverage.bedGraph")
+    futures, stop = {}, threading.Event()
+    pool = ThreadPoolExecutor(max_workers=max(2, len(os.sched_getaffinity(0)) - 1))
+
+    def watch():
+        prefix, suffix = os.path.basename(gbg) + "_penalty=", "_loss.tsv"
+        while True:
+            done = stop.is_set()  # (one more look after the search has returned)
+            for name in os.listdir(str(gdir)):
+                if name.startswith(prefix) and name.endswith(suffix):
+                    pen = name[len(prefix):-len(suffix)]
+                    if pen not in futures and os.path.getsize(os.path.join(str(gdir), name)) > 0:
+                        futures[pen] = pool.submit(_oracle_model, bg, pen)
+            if done:
+                return
+            time.sleep(0.05)
+    watcher = threading.Thread(target=watch)
+    watcher.start()
+    try:
+        fit = psd.sequentialSearch_dir(str(gdir), peaks_int)
+    finally:
+        stop.set()
+        watcher.join()
     gpu_s = time.time() - t0
     got_pen = [psd.paste(float(p)) for p in fit.others["penalty"]]
-    with ThreadPoolExecutor(max_workers=len(os.sched_getaffinity(0))) as pool:
-        known = dict(zip(got_pen, pool.map(lambda pen: _oracle_model(bg, pen), got_pen)))
+    assert sorted(futures) == sorted(got_pen)
+    known = {pen: futures[pen].result() for pen in got_pen}
+    pool.shutdown()
     trace = _oracle_search(str(odir), peaks_int, known=known)
     assert got_pen == [m["penalty"] for m in trace]
     assert list(fit.others["peaks"]) == [m["peaks"] for m in trace]
@@ -439,7 +466,10 @@ def test_batch_with_duplicate_problems(psd, oracle_det, tmp_path, n_bins=2000):
     """The same (bedGraph, penalty) pair listed twice in a batch names one pair of output
     files: it is solved once (two writer threads on the same paths would race) and both
     entries report the same status; a second database name is left as the first is.  The
-    directory batch dedupes the same way (one _timing.tsv, both flagged not cached)."""
+    same file under ANOTHER name (a symlink) names other output files: they are written too
+    (round 3 skipped them and still reported success), from the one dynamic program the pair
+    needs.  The directory batch dedupes the same way (one _timing.tsv, both flagged not
+    cached)."""
     import ctypes
     from peaksegdisk_amd import _native, synthetic
     cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=31)
@@ -465,8 +495,10 @@ def test_batch_with_duplicate_problems(psd, oracle_det, tmp_path, n_bins=2000):
                 open("%s_penalty=%s%s" % (obg, pen, suffix), "rb").read()
     want = os.path.getsize("%s_penalty=25.db" % obg)
     assert [os.path.getsize(p) for p in dbs[:3]] == [want] * 3
-    # the alias was recognised: nothing was written under its own name
-    assert not os.path.exists(link + "_penalty=25_loss.tsv")
+    # the alias names its own output files: the reference would have written them
+    for suffix in ("_segments.bed", "_loss.tsv"):
+        assert open(link + "_penalty=25" + suffix, "rb").read() == \
+            open("%s_penalty=25%s" % (obg, suffix), "rb").read()
     # directory batch: the same pair twice
     dirs = arr([str(d), str(d)])
     st2 = (ctypes.c_int * 2)(9, 9)
@@ -496,11 +528,17 @@ def test_arena_regrowth_resumes_instead_of_repeating(psd, oracle_det, tmp_path, 
     problems = [(0, float(p)) for p in pens]
     monkeypatch.setenv("PEAKSEG_HIP_NO_CHECKPOINT", "1")
     monkeypatch.setenv("PEAKSEG_HIP_PIECES_PER_FUNCTION", "1")
+    # round 4: the arena normally grows WHILE the kernel runs (next test); this test is about
+    # what happens when that cannot keep up or is switched off.  Small blocks: the usual 2^19
+    # pieces would hold this whole problem set.
+    monkeypatch.setenv("PEAKSEG_HIP_NO_LIVE_GROWTH", "1")
+    monkeypatch.setenv("PEAKSEG_HIP_ARENA_BLOCK_LOG2", "14" if n_bins >= 10000 else "12")
     pset = ProblemSet([(cnt, w)], problems)
     pset.solve()
     launches, steps = pset.solve_stats
     assert launches >= 2, "the arena was never exhausted"
     assert steps == n_bins * len(pens), (launches, steps)
+    assert pset.arena_stats[2] == 0
     bg = str(tmp_path / "coverage.bedGraph")
     synthetic.write_bedgraph(bg, cs, ce, cnt)
     want = []
@@ -531,3 +569,53 @@ def test_arena_regrowth_resumes_instead_of_repeating(psd, oracle_det, tmp_path, 
         assert np.array_equal(got[4], want[i][4])
         assert np.array_equal(got[5].view(np.uint64), want[i][5].view(np.uint64))
     rerun.close()
+
+
+@GPU
+def test_arena_grows_while_the_kernel_runs(psd, oracle_det, tmp_path, monkeypatch, n_bins=200000,
+                                           block_log2=""):
+    """Round 4: every arena block is an address range of its own, so the host can map blocks
+    while the kernel runs (tools/vmm_block_probe.cpp; behind ONE range the mapping calls wait
+    for the kernel).  A set is created with only its first blocks mapped; a second host thread
+    maps ahead of what the waves have taken.  With an estimate that is far too small (one piece
+    per function) the solve still needs ONE launch, parks nothing, computes every data point
+    once, has mapped blocks under the kernel, and the store -- spread over blocks that did not
+    exist at launch -- equals the oracle's database byte for byte.  The same with plain
+    allocations instead of the virtual-memory calls (PEAKSEG_HIP_NO_VMM=1)."""
+    from peaksegdisk_amd import ProblemSet, synthetic
+    cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=23)
+    w = (ce - cs).astype(np.int32)
+    pens = ["0.3", "7", "60", "500", "4000", "30000", "200000", "1000000"]
+    problems = [(0, float(p)) for p in pens]
+    monkeypatch.setenv("PEAKSEG_HIP_NO_CHECKPOINT", "1")
+    monkeypatch.setenv("PEAKSEG_HIP_PIECES_PER_FUNCTION", "1")
+    if block_log2:
+        monkeypatch.setenv("PEAKSEG_HIP_ARENA_BLOCK_LOG2", block_log2)
+    bg = str(tmp_path / "coverage.bedGraph")
+    synthetic.write_bedgraph(bg, cs, ce, cnt)
+    want_db = {}
+    for no_vmm in (False, True):
+        if no_vmm:
+            monkeypatch.setenv("PEAKSEG_HIP_NO_VMM", "1")
+        pset = ProblemSet([(cnt, w)], problems)
+        held_before = pset.hbm_bytes
+        block_pieces, blocks_before, _ = pset.arena_stats
+        pset.solve()
+        assert pset.solve_stats == (1, n_bins * len(pens)), pset.solve_stats
+        _, blocks_after, live = pset.arena_stats
+        assert live > 0 and blocks_after == blocks_before + live, (blocks_before, blocks_after, live)
+        assert pset.arena_bytes_used > blocks_before * block_pieces * 20
+        assert pset.hbm_bytes == held_before + live * block_pieces * 20
+        for i in (1, 4, 7):
+            assert pset.result(i).status == 0
+            if i not in want_db:
+                db_o = str(tmp_path / ("o%d.db" % i))
+                assert oracle_det.solve(bg, pens[i], db_o) == 0
+                want_db[i] = open(db_o, "rb").read()
+            db_g = str(tmp_path / ("g%d_%d.db" % (i, no_vmm)))
+            pset.export_db(i, ce, db_g)
+            assert open(db_g, "rb").read() == want_db[i], (pens[i], no_vmm)
+        # a second solve finds the arena it needs: nothing is mapped, one launch
+        pset.solve()
+        assert pset.solve_stats == (1, n_bins * len(pens)) and pset.arena_stats[2] == 0
+        pset.close()

@@ -1,0 +1,206 @@
+"""Round-4 parity and robustness tests on an MI355X (through the C ABI).
+
+  * the two search fixtures the reference's tests hold and rounds 1-3 skipped:
+    `sequentialSearch_dir(data.dir, most.peaks-1L)` on Mono27ac
+    (tests/testthat/test-TRAVIS-sequentialSearch.R:31-35: the small-penalty end of the search,
+    where the next penalty approaches 0 and the "not a new model" exits fire) and
+    "peaks.int=5 but max=2 peaks for N=6 data" (tests/testthat/test-CRAN-sequentialSearch.R:22-26);
+  * parked problems whose functions are too long for a park slot (the overflow pool), over
+    several arena exhaustions in one solve;
+  * the spin bounds that guard the waves' hand-shakes against a hang, measured against the
+    slowest legitimate step.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from test_gpu_round3 import _oracle_search
+
+GPU = pytest.mark.gpu
+
+SIX_POINTS = [(0, 1, 3), (1, 2, 9), (2, 3, 18), (3, 4, 15), (4, 5, 20), (5, 6, 2)]
+
+
+@pytest.fixture(scope="module")
+def psd():
+    import __graft_entry__ as entry
+    entry.build_hip()
+    entry.build_oracle()
+    import peaksegdisk_amd
+    from peaksegdisk_amd import _native
+    assert _native.lib.peakseg_hip_device_count() >= 1, "no HIP device: GPU tests need an MI355X"
+    return peaksegdisk_amd
+
+
+def _search_dirs(tmp_path, text=None):
+    gdir = tmp_path / "gpu" / "chr11-60000-580000"
+    odir = tmp_path / "oracle" / "chr11-60000-580000"
+    for d in (gdir, odir):
+        d.mkdir(parents=True)
+        if text is None:
+            shutil.copy(os.path.join(GOLDEN, "Mono27ac.bedGraph"), str(d / "coverage.bedGraph"))
+        else:
+            (d / "coverage.bedGraph").write_text(text)
+    return gdir, odir
+
+
+def check_search_against_oracle_loop(psd, gdir, odir, target):
+    """sequentialSearch_dir on gdir against the reference's loop driven by the oracle on odir:
+    penalty strings (the file names), peaks, iteration/under/over columns, the chosen model and
+    every model's two files."""
+    fit = psd.sequentialSearch_dir(str(gdir), target)
+    trace = _oracle_search(str(odir), target)
+    got_pen = [psd.paste(float(p)) for p in fit.others["penalty"]]
+    assert got_pen == [m["penalty"] for m in trace]
+    assert list(fit.others["peaks"]) == [m["peaks"] for m in trace]
+    assert list(fit.others["iteration"]) == [1, 1] + list(range(2, len(trace)))
+    for m in trace:
+        pre_g = "%s_penalty=%s" % (str(gdir / "coverage.bedGraph"), m["penalty"])
+        pre_o = "%s_penalty=%s" % (str(odir / "coverage.bedGraph"), m["penalty"])
+        for suffix in ("_segments.bed", "_loss.tsv"):
+            assert open(pre_g + suffix, "rb").read() == open(pre_o + suffix, "rb").read(), m
+    return fit, trace
+
+
+@GPU
+def test_search_for_most_peaks_minus_one(psd, tmp_path, text=None, most_peaks=3199):
+    """test-TRAVIS-sequentialSearch.R:31-35: `most.peaks <- fit$others[penalty==0, peaks]`,
+    then `sequentialSearch_dir(data.dir, most.peaks-1L)` "returns something".  On Mono27ac the
+    penalty-0 model has 3199 peaks, so the target is 3198: the search works its
+    way down to penalties near 0.  Here it must ask for exactly the penalties the reference's
+    loop asks for when the oracle computes the models, end by the same rule, and return a model
+    with at most 3198 peaks."""
+    gdir, odir = _search_dirs(tmp_path, text)
+    if most_peaks is None:  # other data than Mono27ac: what the penalty-0 model has
+        from test_gpu_round3 import _oracle_model
+        probe = tmp_path / "probe"
+        probe.mkdir()
+        shutil.copy(str(odir / "coverage.bedGraph"), str(probe / "coverage.bedGraph"))
+        most_peaks = _oracle_model(str(probe / "coverage.bedGraph"), "0")["peaks"]
+    fit, trace = check_search_against_oracle_loop(psd, gdir, odir, most_peaks - 1)
+    assert trace[0]["penalty"] == "0" and trace[0]["peaks"] == most_peaks
+    assert trace[1]["penalty"] == "Inf" and trace[1]["peaks"] == 0
+    assert len(trace) > (4 if text is None else 2), "the search ended at once"
+    chosen_peaks = int(fit.loss["peaks"].iloc[0])
+    assert chosen_peaks <= most_peaks - 1
+    # the candidate rule of R/sequentialSearch_dir.R:68-86: the target itself if a model has it,
+    # else the simpler model of the final bracket
+    peaks = [m["peaks"] for m in trace]
+    if most_peaks - 1 in peaks:
+        assert chosen_peaks == most_peaks - 1
+    else:
+        assert chosen_peaks == max(p for p in peaks if p < most_peaks - 1)
+    pens = [float(m["penalty"]) for m in trace[2:]]
+    assert min(pens) < 1.0 or text is not None, pens  # the small-penalty end was reached
+
+
+@GPU
+def test_search_with_too_many_peaks_on_six_points(psd, tmp_path):
+    """test-CRAN-sequentialSearch.R:8-26: six data points, `sequentialSearch_dir(data.dir, 5L)`
+    is an error, "peaks.int=5 but max=2 peaks for N=6 data" -- after the two models of the first
+    iteration have been computed (penalty 0 is a dynamic program on the GPU), which leave their
+    files.  Through the C ABI and through the Python mirror; a feasible target on the same
+    data follows the oracle-driven loop."""
+    from peaksegdisk_amd import _native
+    text = "".join("chr1\t%d\t%d\t%d\n" % r for r in SIX_POINTS)
+    gdir, odir = _search_dirs(tmp_path, text)
+    rows = (_native.PsdSearchRow * 16)()
+    n = ctypes.c_int()
+    chosen = ctypes.c_int()
+    st = _native.lib.PeakSegFPOP_sequential_search(os.fsencode(str(gdir)), 5, 0, 16, rows,
+                                                   ctypes.byref(n), ctypes.byref(chosen))
+    assert st == _native.ERROR_SEARCH_TOO_MANY_PEAKS
+    assert _native.last_error() == "peaks.int=5 but max=2 peaks for N=6 data"
+    assert n.value == 2 and chosen.value == -1
+    assert [rows[k].penalty_str.decode() for k in range(2)] == ["0", "Inf"]
+    assert rows[0].peaks == 2 and rows[0].bases == 6 and rows[1].peaks == 0  # 2 peaks
+    for pen in ("0", "Inf"):
+        assert os.path.exists("%s_penalty=%s_loss.tsv" % (str(gdir / "coverage.bedGraph"), pen))
+    with pytest.raises(ValueError, match="peaks.int=5 but max=2 peaks for N=6 data"):
+        psd.sequentialSearch_dir(str(gdir), 5)
+    # max=2 itself and the one-peak model are found, by the reference's sequence
+    for target in (2, 1):
+        fit, trace = check_search_against_oracle_loop(psd, gdir, odir, target)
+        assert int(fit.loss["peaks"].iloc[0]) <= target
+
+
+@GPU
+def test_parked_long_functions_survive_several_exhaustions(psd, oracle_det, tmp_path, monkeypatch,
+                                                           n_bins=6000):
+    """a parked problem whose functions exceed a park slot keeps them
+    in the overflow pool from the launch that parked it until the workgroup that resumes it
+    has read them back; the pool used to be emptied before EVERY launch, so a problem that
+    parked again early in a relaunch could overwrite what a still-queued workgroup had not
+    loaded yet.  Adversarial counts (functions of hundreds of pieces), an arena far too small,
+    no growth under the kernel: several exhaustions in one solve, every park through the
+    overflow pool, and the stores equal the oracle's."""
+    from peaksegdisk_amd import ProblemSet, synthetic
+    cs, ce, cnt = synthetic.increasing_coverage(n_bins)
+    pens = ["100", "300", "1000", "30"]
+    monkeypatch.setenv("PEAKSEG_HIP_NO_CHECKPOINT", "1")
+    monkeypatch.setenv("PEAKSEG_HIP_PIECES_PER_FUNCTION", "1")
+    monkeypatch.setenv("PEAKSEG_HIP_NO_LIVE_GROWTH", "1")
+    monkeypatch.setenv("PEAKSEG_HIP_ARENA_BLOCK_LOG2", "14" if n_bins >= 4000 else "12")
+    pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, float(p)) for p in pens])
+    pset.solve()
+    launches, steps = pset.solve_stats
+    parks, pool_pieces = pset.park_stats
+    assert launches >= 3, "fewer than two exhaustions: %r" % (pset.solve_stats,)
+    assert steps == n_bins * len(pens), "a problem was restarted instead of resumed"
+    assert parks >= 2 and pool_pieces > 128 * 2, (parks, pool_pieces)
+    bg = str(tmp_path / "coverage.bedGraph")
+    synthetic.write_bedgraph(bg, cs, ce, cnt)
+    for i, pen in enumerate(pens):
+        r = pset.result(i)
+        assert r.status == 0 and (r.max_intervals > 128 or pen == "30")
+        db_o = str(tmp_path / ("o%d.db" % i))
+        assert oracle_det.solve(bg, pen, db_o) == 0
+        db_g = str(tmp_path / ("g%d.db" % i))
+        pset.export_db(i, ce, db_g)
+        assert open(db_g, "rb").read() == open(db_o, "rb").read(), pen
+    pset.close()
+
+
+@GPU
+def test_spin_bounds_leave_three_orders_of_magnitude(psd, tmp_path, n_bins=30000):
+    """The waves of a workgroup meet through LDS flags (step_sync, the helper mailboxes) with a
+    bound on the number of polls, so that a lost wave becomes an error status instead of a hang
+    (fpop_kernels.h SPIN_LIMIT, fpop_wave.h MAIL_SPIN_LIMIT: 2^26 polls).  The bound must never
+    be reached by a wave that is merely slow.  A build with -DPSD_SPIN_STATS records the largest
+    poll count of every wait; on the slowest legitimate steps there are -- lists in HBM,
+    functions of several hundred pieces, chunk 0's Newton solves running to their 100-step cap
+    (adversarial counts, penalty 100) -- it must stay below a thousandth of the bound."""
+    import __graft_entry__ as entry
+    from peaksegdisk_amd import ProblemSet, _native, synthetic
+    csrc = os.path.join(ROOT, "peaksegdisk_amd", "csrc")
+    lib_path = str(tmp_path / "libpeaksegdisk_hip_spin.so")
+    subprocess.run([entry.HIPCC, "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17",
+                    "-ffp-contract=off", "-fPIC", "-shared", "-DPSD_SPIN_STATS",
+                    "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+                    os.path.join(csrc, "peakseg_hip.cpp"), "-o", lib_path], check=True)
+    lib = _native.declare(ctypes.CDLL(lib_path))
+    lib.peakseg_hip_spin_limit.restype = ctypes.c_longlong
+    limit = lib.peakseg_hip_spin_limit()
+    assert limit == 1 << 26
+    cs, ce, cnt = synthetic.increasing_coverage(n_bins)
+    pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, 100.0)], lib=lib)
+    pset.solve()
+    r = pset.result(0)
+    assert r.status == 0 and r.spill_steps > n_bins - 2000 and r.max_intervals > 300
+    worst = lib.peakseg_hip_problem_set_max_spin(pset._h, 0)
+    pset.close()
+    # ... and the LDS-resident latency path on ordinary data
+    cs, ce, cnt = synthetic.poisson_coverage(50000, seed=3)
+    pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, 0.5), (0, 2000.0)], lib=lib)
+    pset.solve()
+    worst_lds = max(lib.peakseg_hip_problem_set_max_spin(pset._h, p) for p in range(2))
+    pset.close()
+    print("largest poll count of a wait: %d with the lists in HBM, %d in LDS; bound %d"
+          % (worst, worst_lds, limit))
+    assert 0 < worst_lds and 0 < worst
+    assert max(worst, worst_lds) * 1000 < limit
