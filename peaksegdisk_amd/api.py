@@ -189,7 +189,10 @@ def _read_table(path, names):
     """fread(file=..., col.names=names) of one of the solver's tab-separated files."""
     if os.path.getsize(path) == 0:
         raise ValueError("empty file %s" % path)
-    return pd.read_csv(path, sep="\t", header=None, names=names, na_filter=False)
+    # (round_trip: the default parser of read_csv is off by an ulp on some 20-digit fields,
+    # and a penalty read back from _loss.tsv must print as the string that named the file)
+    return pd.read_csv(path, sep="\t", header=None, names=names, na_filter=False,
+                       float_precision="round_trip")
 
 
 def _first_last_line(path, names):

@@ -88,30 +88,38 @@ PSD_D ArenaPtr arena_at(const DeviceArgs &a, unsigned long long off) {
                    off & ((1ull << blg) - 1ull));
 }
 
+/* The three addresses of the current chunk run are needed once per data point, by the lanes
+ * that store the record: they live in LDS (g_sm.cur_ptr: one broadcast read next to the reads of
+ * the record itself), not in six scalar registers that the whole loop would carry -- the latency
+ * build spills scalar registers as it is (cursor in registers: 2172 ms, in LDS: 2120 ms on
+ * 200 k bins x 64, profiles/r04/ab_cursor_in_lds_packed_flag_newton_trim.log). */
 struct ArenaCursor {
   unsigned long long base; /* first piece of the current chunk run */
-  gdouble *mx, *prv;       /* ... and where it lives */
-  gint *di;
   int used, room;
   int store; /* 0: the forward pass of the checkpointed store keeps no per-step records */
 };
 PSD_D void cursor_clear(ArenaCursor &cur, int store) {
   cur.base = 0;
-  cur.mx = cur.prv = nullptr;
-  cur.di = nullptr;
   cur.used = 0;
   cur.room = 0;
   cur.store = store;
 }
 PSD_D void cursor_point(const DeviceArgs &a, ArenaCursor &cur, unsigned long long base, int room) {
   const ArenaPtr q = arena_at(a, base);
+  wave_sync();
+  if (lane_id() == 0) {
+    g_sm.cur_ptr[wave_id() & 1][0] = (unsigned long long)q.mx;
+    g_sm.cur_ptr[wave_id() & 1][1] = (unsigned long long)q.prv;
+    g_sm.cur_ptr[wave_id() & 1][2] = (unsigned long long)q.di;
+  }
+  wave_sync();
   cur.base = base;
-  cur.mx = q.mx;
-  cur.prv = q.prv;
-  cur.di = q.di;
   cur.used = 0;
   cur.room = room;
 }
+PSD_D gdouble *cursor_mx() { return (gdouble *)g_sm.cur_ptr[wave_id() & 1][0]; }
+PSD_D gdouble *cursor_prv() { return (gdouble *)g_sm.cur_ptr[wave_id() & 1][1]; }
+PSD_D gint *cursor_di() { return (gint *)g_sm.cur_ptr[wave_id() & 1][2]; }
 
 /* Reserve arena room for a function of n pieces: the next run of whole chunks for this wave
  * (cold: once per chunk of 2^ar_chunk_log2 pieces), inside ONE block.  Returns the first piece
@@ -186,9 +194,9 @@ PSD_D bool arena_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &f, i
   for (int base = 0; base < n; base += WAVE) {
     int i = base + lane;
     if (i < n) {
-      cur.mx[at + i] = f.mx(i);
-      cur.prv[at + i] = f.prv(i);
-      cur.di[at + i] = f.di(i);
+      cursor_mx()[at + i] = f.mx(i);
+      cursor_prv()[at + i] = f.prv(i);
+      cursor_di()[at + i] = f.di(i);
     }
   }
   if (lane == 0)
@@ -229,9 +237,9 @@ PSD_D bool scale_add_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &
       f.Log(i) = lo * inv_cum_weight;
       f.Con(i) = co * inv_cum_weight;
       if (store) {
-        cur.mx[at + i] = mx;
-        cur.prv[at + i] = prv;
-        cur.di[at + i] = di;
+        cursor_mx()[at + i] = mx;
+        cursor_prv()[at + i] = prv;
+        cursor_di()[at + i] = di;
       }
     }
   }
@@ -969,7 +977,7 @@ PSD_D void forward_body(const DeviceArgs &a) {
   r.prev_log_mean = 0.0;
   r.prev_seg_end = -1;
   unsigned sync_no = 0; /* parity slot of the abort flags: one per barrier */
-  const long long t_begin = cycle_now();
+  if (lane == 0) g_sm.t_begin[chain] = cycle_now(); /* (in LDS: read once, at the end) */
   bool resumed_abort = false;
   if (!CKPT && a.prob_resume != nullptr) {
     /* A problem parked by an earlier launch (the arena had run out): its two functions, the
@@ -1257,7 +1265,7 @@ PSD_D void forward_body(const DeviceArgs &a) {
   if (lane == 0 && a.prof) {
     long long *dst = a.prof + ((long long)p * 2 + chain) * N_PROF;
     for (int i = 0; i < N_PROF; i++) dst[i] = g_sm.prof[chain][i];
-    dst[PROF_TOTAL] = cycle_now() - t_begin;
+    dst[PROF_TOTAL] = cycle_now() - g_sm.t_begin[chain];
   }
 #endif
   if (chain == 1) {
@@ -1275,7 +1283,7 @@ PSD_D void forward_body(const DeviceArgs &a) {
 #ifdef PSD_SPIN_STATS
     for (int w = 0; w < 4; w++) r.max_spin = g_sm.spin_max[w] > r.max_spin ? g_sm.spin_max[w] : r.max_spin;
 #endif
-    r.cycles = cycle_now() - t_begin;
+    r.cycles = cycle_now() - g_sm.t_begin[chain];
     if (lane == 0) a.result[p] = r;
   }
 }

@@ -112,6 +112,8 @@ struct SharedBlock {
 #ifdef PSD_SPIN_STATS
   int spin_max[4];
 #endif
+  long long t_begin[2];             /* cycle counter at the start of each chain wave */
+  unsigned long long cur_ptr[2][3]; /* where each chain's current arena run lives (ArenaCursor) */
 };
 
 PSD_LDS SharedBlock g_sm;

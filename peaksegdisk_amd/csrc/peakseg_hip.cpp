@@ -1590,8 +1590,32 @@ extern "C" int peakseg_hip_problem_set_export_db(psd_problem_set *s, int p, cons
   std::vector<long long> table((size_t)4 * N, 0);
   long long pos = 32ll * N;
   std::vector<char> body;
-  std::vector<double> mx, prv;
-  std::vector<int> di;
+  /* the records are read from host copies of the arena's blocks (two at a time: the two chains
+   * of a problem write into different chunk runs), not with three small copies per function */
+  const int blg = s->d.ar_block_log2;
+  const size_t block_bytes = arena_block_bytes(s);
+  struct HostBlock {
+    size_t blk = (size_t)-1;
+    std::vector<char> bytes;
+    unsigned long long used = 0;
+  } cache[2];
+  unsigned long long tick = 0;
+  auto host_block = [&](size_t blk) -> const char * {
+    for (auto &c : cache)
+      if (c.blk == blk) {
+        c.used = ++tick;
+        return c.bytes.data();
+      }
+    HostBlock &c = cache[0].used <= cache[1].used ? cache[0] : cache[1];
+    if (blk >= s->arena_blocks.size()) return nullptr;
+    c.bytes.resize(block_bytes);
+    if (hipMemcpy(c.bytes.data(), s->arena_blocks[blk].base, block_bytes, hipMemcpyDeviceToHost) !=
+        hipSuccess)
+      return nullptr;
+    c.blk = blk;
+    c.used = ++tick;
+    return c.bytes.data();
+  };
   for (int t = 0; t < N; t++) {
     for (int which = 0; which < 2; which++) {
       int element = which == 0 ? N + t : t;
@@ -1599,20 +1623,16 @@ extern "C" int peakseg_hip_problem_set_export_db(psd_problem_set *s, int p, cons
       unsigned long long r = ref[(size_t)element];
       unsigned long long off = r >> psd::FN_COUNT_BITS;
       int n = (int)(r & ((1ull << psd::FN_COUNT_BITS) - 1));
-      mx.resize((size_t)n);
-      prv.resize((size_t)n);
-      di.resize((size_t)n);
       /* the record's block and its three arrays (fpop_types.h) */
-      const int blg = s->d.ar_block_log2;
-      const size_t blk = (size_t)(off >> blg), w = (size_t)(off & ((1ull << blg) - 1ull));
-      const char *bb = blk < s->arena_blocks.size() ? (const char *)s->arena_blocks[blk].base : nullptr;
-      if (!bb ||
-          hipMemcpy(mx.data(), bb + w * 8, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-          hipMemcpy(prv.data(), bb + ((size_t)8 << blg) + w * 8, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-          hipMemcpy(di.data(), bb + ((size_t)16 << blg) + w * 4, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+      const size_t w = (size_t)(off & ((1ull << blg) - 1ull));
+      const char *bb = host_block((size_t)(off >> blg));
+      if (!bb || w + (size_t)n > ((size_t)1 << blg)) {
         fclose(f);
         return -1;
       }
+      const double *mx = (const double *)bb + w;
+      const double *prv = (const double *)(bb + ((size_t)8 << blg)) + w;
+      const int *di = (const int *)(bb + ((size_t)16 << blg)) + w;
       table[(size_t)2 * element] = pos;
       int size = 20 * n + 8;
       size_t at = body.size();

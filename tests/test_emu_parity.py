@@ -27,7 +27,9 @@ def psd():
     subprocess.run(["make", "-s", "-C", EMU_DIR], check=True)
     import peaksegdisk_amd
     from peaksegdisk_amd import _native
-    emu = _native.declare(ctypes.CDLL(os.path.join(EMU_DIR, "_build", "libpeaksegdisk_emu.so")))
+    # (PSD_EMU_LIB_OVERRIDE: an emulator build of an experimental source tree, for A/B work)
+    emu = _native.declare(ctypes.CDLL(os.environ.get(
+        "PSD_EMU_LIB_OVERRIDE", os.path.join(EMU_DIR, "_build", "libpeaksegdisk_emu.so"))))
     real = _native.lib
     _native.lib = emu
     try:

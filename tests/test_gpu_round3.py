@@ -135,6 +135,26 @@ out = gather_segment_tables(tables, dist, 0, always_collective=True)
 assert len(out) == 1 and len(out[0]) == len(tables)
 for (s0, m0), (s1, m1) in zip(tables, out[0]):
     assert np.array_equal(s0, s1) and np.array_equal(m0.view(np.uint64), m1.view(np.uint64))
+# round 4: a solved problem set's tables, packed IN HBM by the library and handed to the
+# collective as device tensors that alias the packed arrays (no per-problem copy, no numpy on
+# the sending side): what every rank > 0 sends to rank 0
+from peaksegdisk_amd import ProblemSet, synthetic
+from peaksegdisk_amd.parallel import gather_problem_set, packed_payload
+cs, ce, cnt = synthetic.poisson_coverage(30000, seed=9)
+pens = [0.0, 0.4, 30.0, 2500.0, 1e6]
+pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, p) for p in pens])
+pset.solve()
+payload = packed_payload(pset, dev)
+assert all(t.is_cuda for t in payload)
+rows, ptr_s, ptr_m, total = pset.pack_tables()
+assert payload[1].data_ptr() == ptr_s and payload[2].data_ptr() == ptr_m  # aliases, not copies
+got = gather_problem_set(pset, dist, 0, always_collective=True, extra=np.arange(3.0))
+assert len(got) == 1 and list(got[0][1]) == [0.0, 1.0, 2.0]
+for p, (gs, gm) in enumerate(got[0][0]):
+    s0, m0 = pset.segments(p)
+    assert len(s0) == pset.result(p).n_segments
+    assert np.array_equal(gs, s0) and np.array_equal(gm.view(np.uint64), m0.view(np.uint64))
+pset.close()
 dist.barrier()
 dist.destroy_process_group()
 print("rccl-one-rank ok")
@@ -145,9 +165,11 @@ print("rccl-one-rank ok")
 def test_pack_tables_through_device_tensors(psd):
     """The gather's payload (parallel.pack_tables) survives the trip numpy -> HBM -> numpy
     bit for bit, empty and ragged tables included, and the collective part of
-    gather_segment_tables runs on RCCL with one rank on this GPU.  In a child process: torch
-    ships its own HIP runtime, which must be the first one loaded (bench.py imports torch
-    before the library for the same reason)."""
+    gather_segment_tables runs on RCCL with one rank on this GPU; and a solved problem set's
+    tables go HBM -> RCCL: packed on the device by the library, aliased as cuda tensors, sent
+    from there (gather_problem_set).  In a child process: torch ships its own HIP runtime,
+    which must be the first one loaded (bench.py imports torch before the library for the
+    same reason)."""
     import bench
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

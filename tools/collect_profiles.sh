@@ -31,4 +31,8 @@ rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INS
   SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS --kernel-trace \
   -d "$OUT/pmc_sq2" -o pmc -- \
   python3 "$REPO/bench.py" --bins 20000 --steps 1 --warmup 0 --no-cpu > "$OUT/pmc_sq2.log" 2>&1 || exit 1
+# stamped diagnostic build: phase shares and wave-level Newton trips (input of tools/chain_floor.py)
+echo "== phase profile (stamped build, 50k bins x 8 penalties)"
+cd "$REPO" && python3 tools/phase_profile.py 50000 8 > "$OUT/phase_shares.log" 2>&1 || exit 1
+tail -4 "$OUT/phase_shares.log" | cut -c1-200
 find "$OUT" -name "*.db" | head -20

@@ -14,8 +14,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# (slot 8 is PROF_SERIAL: in the walks it times the all-pairs SPECULATION ROUND -- the Newton
+# solves of every (start, later piece) pair -- and in the envelope the sequential replay, which
+# has run 0 times on every data set so far; rounds 1-3 labelled it "env serial")
 NAMES = ["pre(costs+classes)", "walk(state machine+roots)", "env table", "env classify",
-         "env compact", "scale_add", "arena", "barrier wait", "env serial", "TOTAL",
+         "env compact", "scale_add", "arena", "barrier wait", "speculation round", "TOTAL",
          "c.load", "c.mid", "c.opt", "c.small", "c.large", "c.tail",
          "it.spec", "it.small", "it.large", "-", "s.assign", "s.load", "s.newton", "-"]
 NP = 24

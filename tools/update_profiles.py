@@ -66,6 +66,14 @@ def main():
     with open(os.path.join(dst, "pmc_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
+    phase = os.path.join(SRC, "phase_shares.log")
+    if os.path.exists(phase):
+        shutil.copy(phase, os.path.join(dst, "phase_shares_final_kernel.log"))
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "chain_floor.py"),
+                        os.path.join(dst, "phase_shares_final_kernel.log"),
+                        os.path.join(dst, "pmc_traffic.json"),
+                        os.path.join(dst, "chain_floor.json")], check=True,
+                       stdout=subprocess.DEVNULL)
 
 
 if __name__ == "__main__":
