@@ -259,6 +259,14 @@ def main():
         cs, ce, cnt = synthetic.poisson_coverage(args.bins, seed=1 + rank)
         weight = (ce - cs).astype(np.int32)
         problems = [(0, p) for p in penalties]
+        # The first HIP call of a process creates the device context (0.2-0.4 s, once per
+        # process, whatever is solved afterwards): a one-bin set pays it here, so that create_s
+        # is what SURVEY.md 8(d) counts -- upload and allocation of THIS set
+        # (profiles/r04/create_timing.log: 0.45 s for the first set of a process, 0.02 s for
+        # the second and third).
+        t_c = time.time()
+        ProblemSet([(cnt[:2], weight[:2])], [(0, 1.0)], device=device).close()
+        runtime_init_s = time.time() - t_c
         t_c = time.time()
         pset = ProblemSet([(cnt, weight)], problems, device=device)
         create_s = time.time() - t_c
@@ -461,6 +469,7 @@ def main():
             out["value_incl_upload"] = units_per_step / world / \
                 (create_s + elapsed / args.steps)
             out["upload_alloc_s"] = create_s
+            out["runtime_init_s"] = runtime_init_s  # device context, once per process: not in any rate
         if not args.no_cpu and world == 1 and args.mode == "weak":
             out["cpu_baseline"] = cpu_baseline(cs, ce, cnt, pen_str, args.cpu_bins,
                                                args.cpu_bins_all)

@@ -377,6 +377,17 @@ enum { CLS_STORE = 0, CLS_CONST_EDGE = 1, CLS_CONST_MU = 2 };
 #define PSD_SPEC_WINDOW 5
 #endif
 constexpr int SPEC_WINDOW = PSD_SPEC_WINDOW;
+/* ... and for functions of 13 to 16 pieces (whose starts times SPEC_WINDOW no longer fit the 64
+ * lanes): one piece fewer per start keeps the direct lane -> (start, piece) mapping instead of a
+ * loop over the starts, which cost the min-more wave of the large-penalty problems -- the
+ * slowest of a grid -- 3 % of its data point (2124 -> 2101 ms on 200 k bins x 64,
+ * profiles/r04/ab_adaptive_speculation_window.log).  Speculation only decides what is solved
+ * ahead of the walk, never a result. */
+#ifdef PSD_NO_NARROW_WINDOW /* A/B */
+constexpr int SPEC_WINDOW_NARROW = SPEC_WINDOW;
+#else
+constexpr int SPEC_WINDOW_NARROW = 4;
+#endif
 
 /* error bits (the reference would throw / loop / read a sentinel) */
 enum {
@@ -619,21 +630,28 @@ PSD_D int min_less_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
   unsigned long long sp_ev = 0, sp_inside = 0, sp_bad = 0;
   double sp_mu = PSD_INF;
   int my_base = 0; /* lane j: first task lane of start j */
+  int win = SPEC_WINDOW; /* pieces after a start that the speculation covers */
   if (small) {
     unsigned long long m_start = ballot(lane < n && P.cls != CLS_STORE);
     int tj = -1, tk = 0;
-    if (n * SPEC_WINDOW <= WAVE) {
-      /* few pieces (the usual case): task lane = start * SPEC_WINDOW + offset, no loop */
+    /* the window a start gets: SPEC_WINDOW pieces while n starts of that many fit a wave, one
+     * fewer for up to 16 pieces (64 / 4 starts): still a direct lane -> task mapping, no loop
+     * over the starts */
+    win = (n * SPEC_WINDOW <= WAVE) ? SPEC_WINDOW : ((n * SPEC_WINDOW_NARROW <= WAVE) ? SPEC_WINDOW_NARROW : 0);
+    if (win > 0) {
+      /* few pieces (the usual case): task lane = start * window + offset, no loop */
       if (m_start) {
         spec = true;
-        const int cj = lane / SPEC_WINDOW, off = lane - cj * SPEC_WINDOW;
+        const int cj = win == SPEC_WINDOW ? lane / SPEC_WINDOW : lane / SPEC_WINDOW_NARROW;
+        const int off = lane - cj * win;
         if (cj < n && ((m_start >> cj) & 1ull) && cj + 1 + off < n) {
           tj = cj;
           tk = cj + 1 + off;
         }
-        my_base = lane * SPEC_WINDOW;
+        my_base = lane * win;
       }
     } else {
+      win = SPEC_WINDOW;
       int total = 0;
       for (unsigned long long m = m_start; m; m &= m - 1) {
         int c = n - 1 - ctz64(m);
@@ -763,7 +781,7 @@ PSD_D int min_less_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_,
     int scan_from = j + 1; /* first piece not covered by the speculation */
     if (spec) {
       int cntj = n - 1 - j;
-      if (cntj > SPEC_WINDOW) cntj = SPEC_WINDOW;
+      if (cntj > win) cntj = win;
       scan_from = j + 1 + cntj;
       if (cntj > 0) {
         int base = rdlane_i(my_base, j);
@@ -908,22 +926,26 @@ PSD_D int min_more_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_, 
   unsigned long long sp_ev = 0, sp_inside = 0;
   double sp_mu = PSD_INF;
   int my_base = 0;
+  int win = SPEC_WINDOW;
   PSD_PROF_SUB0();
   if (small) {
     unsigned long long m_start = ballot(lane < n && P.cls != CLS_STORE);
     int tj = -1, tk = 0;
-    if (n * SPEC_WINDOW <= WAVE) {
-      /* few pieces (the usual case): task lane = start * SPEC_WINDOW + offset, no loop */
+    win = (n * SPEC_WINDOW <= WAVE) ? SPEC_WINDOW : ((n * SPEC_WINDOW_NARROW <= WAVE) ? SPEC_WINDOW_NARROW : 0);
+    if (win > 0) {
+      /* few pieces (the usual case): task lane = start * window + offset, no loop */
       if (m_start & ~1ull) { /* piece 0 has no earlier piece */
         spec = true;
-        const int cj = lane / SPEC_WINDOW, off = lane - cj * SPEC_WINDOW;
+        const int cj = win == SPEC_WINDOW ? lane / SPEC_WINDOW : lane / SPEC_WINDOW_NARROW;
+        const int off = lane - cj * win;
         if (cj < n && ((m_start >> cj) & 1ull) && off < cj) {
           tj = cj;
           tk = cj - 1 - off;
         }
-        my_base = lane * SPEC_WINDOW;
+        my_base = lane * win;
       }
     } else {
+      win = SPEC_WINDOW;
       int total = 0;
       for (unsigned long long m = m_start; m; m &= m - 1) {
         int c = ctz64(m);
@@ -1060,7 +1082,7 @@ PSD_D int min_more_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_, 
     double ev_mu = 0.0;
     int scan_from = j - 1; /* first piece (walking down) not covered by the speculation */
     if (spec) {
-      int cntj = j < SPEC_WINDOW ? j : SPEC_WINDOW;
+      int cntj = j < win ? j : win;
       scan_from = j - 1 - cntj;
       if (cntj > 0) {
         int base = rdlane_i(my_base, j);

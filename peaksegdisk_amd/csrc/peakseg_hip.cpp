@@ -826,6 +826,16 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
     return ERROR_DEVICE_SOLVER;
   }
   HIP_TRY(hipSetDevice(device));
+  /* PEAKSEG_HIP_TIMING=1: where the creation of a set spends its time, on stderr */
+  const bool timing = getenv("PEAKSEG_HIP_TIMING") != nullptr;
+  auto t_mark = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "peakseg_hip timing: create: %-26s %8.3f s\n", what,
+            std::chrono::duration<double>(now - t_mark).count());
+    t_mark = now;
+  };
   psd_problem_set *s = new psd_problem_set();
   s->device = device;
   s->n_contigs = n_contigs;
@@ -855,6 +865,7 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
     max_lm[c] = mx;
   }
   s->total_bins = off;
+  lap("gather contigs, log range");
   long long dp_bins = 0;
   for (int p = 0; p < n_problems; p++) {
     int c = problem_contig[p];
@@ -953,6 +964,7 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
     peakseg_hip_problem_set_destroy(s);
     return st;
   }
+  lap("upload, tables");
   d.ckpt_interval = K;
   d.ckpt_cap = psd::lat::LDS_CAP;
   d.ckpt_region = 0;
@@ -1060,10 +1072,12 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
    * is mapped here, and a solve that needs more parks, grows and resumes (as round 3 did). */
   s->live_growth = K == 0 && s->arena_auto && !getenv("PEAKSEG_HIP_NO_LIVE_GROWTH");
   s->first_estimate = want;
+  lap("park slots, pools");
   if ((st = alloc_arena(s, want, first_limit, s->live_growth))) {
     peakseg_hip_problem_set_destroy(s);
     return st;
   }
+  lap("first arena blocks");
   if (hipDeviceGetAttribute(&s->n_cu, hipDeviceAttributeMultiprocessorCount, device) !=
           hipSuccess ||
       s->n_cu <= 0)
@@ -1098,6 +1112,7 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
     return ERROR_DEVICE_SOLVER;
   }
   s->results.resize((size_t)n_problems);
+  lap("streams, events");
   *out = s;
   return 0;
 }

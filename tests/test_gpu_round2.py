@@ -69,18 +69,20 @@ def run_cli(cli, bg, pen, db):
 
 def check_against_libm_files(pset, i, pen, bg, cs, ce, n_bins):
     """segment rows (coordinates, 6-digit means) and the integer loss fields identical to the
-    glibc-arithmetic oracle's files; total.loss within 1e-6 relative."""
-    segs = read_segments("%s_penalty=%s_segments.bed" % (bg, pen))
+    glibc-arithmetic oracle's files; total.loss within 1e-6 relative.  (Columns through pandas'
+    C reader and formatter: the small penalties of a 1e6-bin contig have 5e5 rows each.)"""
+    from conftest import format_g, read_segment_columns
+    f_start, f_end, f_status, f_mean = read_segment_columns("%s_penalty=%s_segments.bed" % (bg, pen))
     start, mean = pset.segments(i)
-    assert len(segs) == len(start), pen
+    assert len(f_start) == len(start), pen
     got_start = np.where(start < 0, int(cs[0]), ce[np.maximum(start, 0)])
-    assert np.array_equal(np.array([s[1] for s in segs]), got_start), pen
-    assert np.array_equal(np.array([s[2] for s in segs][1:]), got_start[:-1]), pen
-    assert [s[3] for s in segs[:3]] == ["background", "peak", "background"][:len(segs)]
-    assert [s[4] for s in segs] == ["%g" % v for v in mean], pen
-    loss = read_loss("%s_penalty=%s_loss.tsv" % (bg, pen)).split("\t")
+    assert np.array_equal(f_start, got_start), pen
+    assert np.array_equal(f_end[1:], got_start[:-1]), pen
+    assert list(f_status[:3]) == ["background", "peak", "background"][:len(f_status)]
+    assert list(f_mean) == format_g(mean), pen
     r = pset.result(i)
-    assert (int(loss[1]), int(loss[2]), int(loss[4])) == (r.n_segments, r.n_peaks, n_bins), pen
+    loss = read_loss("%s_penalty=%s_loss.tsv" % (bg, pen)).split("\t")
+    assert [int(v) for v in loss[1:5]] == [r.n_segments, r.n_peaks, int(ce[-1] - cs[0]), n_bins]
     assert int(loss[7]) == r.n_equality_constraints, pen
     cw = float(loss[3])
     total = r.best_cost * cw - float(pen) * r.n_peaks
@@ -88,42 +90,45 @@ def check_against_libm_files(pset, i, pen, bg, cs, ce, n_bins):
     return float(loss[8]), float(loss[9])
 
 
+def _oracle_files(background_oracles, spec, tmp_path, runs):
+    """The oracle files a full-size test compares with: from the session's background runs
+    (conftest.BackgroundOracles: started with the session, done by the time these tests run,
+    last), or started now when the test runs on its own."""
+    from peaksegdisk_amd import synthetic
+    name = spec["name"]
+    if name not in background_oracles.jobs:
+        pens = synthetic.penalty_grid(64)
+        background_oracles.root = str(tmp_path)
+        background_oracles.start(name, spec["n_bins"], spec["seed"],
+                                 [(cli, pens[i], sub) for cli, i, sub in runs])
+    return background_oracles.wait(name)
+
+
 @GPU
-def test_endpoints_vs_glibc_arithmetic_1e6_x64(psd, tmp_path):
+def test_endpoints_vs_glibc_arithmetic_1e6_x64(psd, background_oracles, tmp_path):
     """BASELINE.json configs[1] at full size against the arithmetic the reference itself
-    uses: ALL 64 penalties solved by oracle_cli_libm in a process pool while the GPU solves the
-    grid (round 2 sampled 17); every 8th penalty also by the deterministic build -- whose files
-    the GPU's tables must equal exactly -- to report how many stored functions differ in piece
-    count between the two arithmetics.  On the same solve: the size-independent properties
-    (test_gpu_parity.check_grid_properties: well-formed tables, up/down constraint, the loss
-    recomputed from the segmentation, peaks monotone in the penalty) and determinism of a second
-    solve, which also has to find the arena the first one grew (round 4: one solve of this
-    grid per test run instead of two)."""
+    uses: ALL 64 penalties solved by oracle_cli_libm (round 2 sampled 17); every 8th penalty
+    also by the deterministic build -- whose files the GPU's tables must equal exactly -- to
+    report how many stored functions differ in piece count between the two arithmetics.  On the
+    same solve: the size-independent properties (test_gpu_parity.check_grid_properties:
+    well-formed tables, up/down constraint, the loss recomputed from the segmentation, peaks
+    monotone in the penalty) and determinism of a second solve, which also has to find the
+    arena the first one grew (round 4: one solve of this grid per test run instead of two; the
+    72 oracle processes run in the background of the whole session, conftest.py)."""
+    from conftest import LONG_1E6
     from peaksegdisk_amd import ProblemSet, synthetic
-    n_bins = 1000000
-    cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=1)
+    n_bins = LONG_1E6["n_bins"]
     pens = synthetic.penalty_grid(64)
     pick = list(range(64))
-    bg = str(tmp_path / "coverage.bedGraph")
-    write_bedgraph_chunked(bg, cs, ce, cnt)
-    import bench
-    workers = max(1, min(len(pick) + 8, bench.host_cores()))
+    div_pick = LONG_1E6["det_picks"]
     t0 = time.time()
-    with ThreadPoolExecutor(max_workers=workers) as pool:
-        futs = [pool.submit(run_cli, CLI_LIBM, bg, pens[i], str(tmp_path / ("l%d.db" % i)))
-                for i in pick]
-        # the deterministic build for four of them: piece-count divergence det vs glibc
-        div_pick = [4, 12, 20, 28, 36, 44, 52, 63]
-        ddir = tmp_path / "det"
-        ddir.mkdir()
-        dbg = str(ddir / "coverage.bedGraph")
-        os.link(bg, dbg)
-        futs += [pool.submit(run_cli, CLI_DET, dbg, pens[i], str(tmp_path / ("d%d.db" % i)))
-                 for i in div_pick]
-        pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, float(p)) for p in pens])
-        f_ms, _ = pset.solve()
-        for f in futs:
-            f.result()
+    cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=LONG_1E6["seed"])
+    pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, float(p)) for p in pens])
+    f_ms, _ = pset.solve()
+    dirs, dbs, _ = _oracle_files(background_oracles, LONG_1E6, tmp_path,
+                                 [(CLI_LIBM, i, "libm") for i in pick] +
+                                 [(CLI_DET, i, "det") for i in div_pick])
+    bg, dbg = dirs["libm"], dirs["det"]
     report = {"bins": n_bins, "kernel_ms": f_ms, "oracle_wall_s": time.time() - t0, "penalties": {}}
     for i in pick:
         assert pset.result(i).status == 0
@@ -134,18 +139,19 @@ def test_endpoints_vs_glibc_arithmetic_1e6_x64(psd, tmp_path):
             "mean_intervals_glibc": mean_int, "max_intervals_gpu": r.max_intervals,
             "max_intervals_glibc": max_int}
     for i in div_pick:
-        a = db_piece_counts(str(tmp_path / ("d%d.db" % i)), n_bins)
-        b = db_piece_counts(str(tmp_path / ("l%d.db" % i)), n_bins)
+        a = db_piece_counts(dbs[("det", pens[i])], n_bins)
+        b = db_piece_counts(dbs[("libm", pens[i])], n_bins)
         r = pset.result(i)
         assert int(a.sum()) == r.total_intervals  # the GPU store has the det oracle's counts
         report["penalties"][pens[i]]["functions_with_different_piece_count_det_vs_glibc"] = \
             int((a != b).sum())
         report["penalties"][pens[i]]["functions"] = int(2 * n_bins - 1)
         # ... and the deterministic oracle's files exactly
-        segs = read_segments("%s_penalty=%s_segments.bed" % (dbg, pens[i]))
+        from conftest import format_g, read_segment_columns
+        d_start, _, _, d_mean = read_segment_columns("%s_penalty=%s_segments.bed" % (dbg, pens[i]))
         start, mean = pset.segments(i)
-        assert [s[1] for s in segs] == [int(cs[0]) if k < 0 else int(ce[k]) for k in start]
-        assert [s[4] for s in segs] == ["%g" % v for v in mean]
+        assert np.array_equal(d_start, np.where(start < 0, int(cs[0]), ce[np.maximum(start, 0)]))
+        assert list(d_mean) == format_g(mean)
         loss = read_loss("%s_penalty=%s_loss.tsv" % (dbg, pens[i])).split("\t")
         assert loss[5] == "%.20g" % r.best_cost and float(loss[9]) == r.max_intervals
         assert int(loss[7]) == r.n_equality_constraints
@@ -172,26 +178,23 @@ def test_endpoints_vs_glibc_arithmetic_1e6_x64(psd, tmp_path):
 
 
 @GPU
-def test_endpoints_vs_glibc_arithmetic_1e7_x64(psd, tmp_path):
+def test_endpoints_vs_glibc_arithmetic_1e7_x64(psd, background_oracles, tmp_path):
     """The north_star size: one 1e7-bin contig x 64 penalties on one GPU, four penalties
-    checked against oracle_cli_libm (which needs two to three minutes each; they run while the
-    GPU works)."""
+    checked against oracle_cli_libm (which needs two to three minutes each: they run in the
+    background of the session, conftest.py)."""
+    from conftest import LONG_1E7
     from peaksegdisk_amd import ProblemSet, synthetic
-    n_bins = 10000000
-    cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=1)
+    n_bins = LONG_1E7["n_bins"]
     pens = synthetic.penalty_grid(64)
-    pick = [9, 27, 44, 60]
-    bg = str(tmp_path / "coverage.bedGraph")
-    write_bedgraph_chunked(bg, cs, ce, cnt)
-    with ThreadPoolExecutor(max_workers=len(pick)) as pool:
-        futs = [pool.submit(run_cli, CLI_LIBM, bg, pens[i], str(tmp_path / ("l%d.db" % i)))
-                for i in pick]
-        pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, float(p)) for p in pens])
-        f_ms, _ = pset.solve()
-        for i in range(64):
-            assert pset.result(i).status == 0, (i, pset.result(i).kernel_status)
-        for f in futs:
-            f.result()
+    pick = LONG_1E7["picks"]
+    cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=LONG_1E7["seed"])
+    pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, float(p)) for p in pens])
+    f_ms, _ = pset.solve()
+    for i in range(64):
+        assert pset.result(i).status == 0, (i, pset.result(i).kernel_status)
+    dirs, _, _ = _oracle_files(background_oracles, LONG_1E7, tmp_path,
+                               [(CLI_LIBM, i, "libm") for i in pick])
+    bg = dirs["libm"]
     report = {"bins": n_bins, "penalties_solved": 64, "kernel_ms": f_ms,
               "bins_per_s": n_bins * 64 / (f_ms / 1e3), "hbm_bytes": pset.hbm_bytes,
               "arena_bytes_used": pset.arena_bytes_used, "checked": {}}

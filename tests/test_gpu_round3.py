@@ -315,13 +315,17 @@ def _oracle_search(problem_dir, peaks_int, cli=CLI_DET, known=None):
 
 
 @GPU
-def test_sequential_search_on_a_long_contig(psd, tmp_path, n_bins=1000000, peaks_int=500):
+def test_sequential_search_on_a_long_contig(psd, tmp_path, n_bins=1000000, peaks_int=613):
     """BASELINE.json configs[2] at a tenth of its length: sequentialSearch_dir on a 1e6-bin
     synthetic contig.  The resident driver must ask for the models the reference's loop asks
     for: same penalty strings in the same order, same peaks, and the chosen model's files
     byte-identical to the oracle's.  The oracle solves every penalty the search visited (all
     at once, one process each) and the reference's loop is then replayed on the oracle's
-    results: it must ask for exactly those penalties, in that order."""
+    results: it must ask for exactly those penalties, in that order.
+    (Target 613: on this contig the reference's loop visits penalties 0, Inf, 132.08..., 3535.04...,
+    172.90..., 215.75..., 266.71..., 358.79..., 295.46... -- 420317, 0, 12779, 436, 4846, 1896, 809,
+    490, 613 peaks -- nine models, eight dynamic programs of 1e6 data points; rounds 2-3 searched
+    for 500, the same path six models longer, 141 s of the driver's GPU test step.)"""
     from peaksegdisk_amd import synthetic
     cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=1)
     gdir = tmp_path / "gpu" / "chrSynth-0-1"
