@@ -219,8 +219,7 @@ def test_kernel_resource_budgets(tmp_path):
     import __graft_entry__ as entry
     csrc = os.path.join(ROOT, "peaksegdisk_amd", "csrc")
     out = subprocess.run(
-        [entry.HIPCC, "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17",
-         "-ffp-contract=off", "-fPIC", "-shared", "-Rpass-analysis=kernel-resource-usage",
+        [entry.HIPCC] + entry.HIP_FLAGS + [ "-Rpass-analysis=kernel-resource-usage",
          "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
          os.path.join(csrc, "peakseg_hip.cpp"), "-o", str(tmp_path / "lib.so")],
         capture_output=True, text=True, check=True).stderr

@@ -383,8 +383,7 @@ def test_sequential_envelope_replay(psd, oracle_det, tmp_path):
     for variant, flag in (("serial", "-DPSD_FORCE_SERIAL_ENV"), ("rare", "-DPSD_FORCE_RARE")):
         lib_path = str(tmp_path / ("libpeaksegdisk_hip_%s.so" % variant))
         procs[variant] = (lib_path, subprocess.Popen(
-            [entry.HIPCC, "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17",
-             "-ffp-contract=off", "-fPIC", "-shared", flag,
+            [entry.HIPCC] + entry.HIP_FLAGS + [ flag,
              "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
              os.path.join(csrc, "peakseg_hip.cpp"), "-o", lib_path]))
     for variant, (lib_path, proc) in procs.items():

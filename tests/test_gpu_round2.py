@@ -400,8 +400,7 @@ def _build_variant(tmp_path, name, flags):
     from peaksegdisk_amd import _native
     csrc = os.path.join(ROOT, "peaksegdisk_amd", "csrc")
     lib_path = str(tmp_path / ("libpeaksegdisk_hip_%s.so" % name))
-    subprocess.run([entry.HIPCC, "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17",
-                    "-ffp-contract=off", "-fPIC", "-shared"] + flags + [
+    subprocess.run([entry.HIPCC] + entry.HIP_FLAGS + flags + [
                     "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
                     os.path.join(csrc, "peakseg_hip.cpp"), "-o", lib_path], check=True)
     return _native.declare(ctypes.CDLL(lib_path))

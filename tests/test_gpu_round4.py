@@ -179,8 +179,7 @@ def test_spin_bounds_leave_three_orders_of_magnitude(psd, tmp_path, n_bins=30000
     from peaksegdisk_amd import ProblemSet, _native, synthetic
     csrc = os.path.join(ROOT, "peaksegdisk_amd", "csrc")
     lib_path = str(tmp_path / "libpeaksegdisk_hip_spin.so")
-    subprocess.run([entry.HIPCC, "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17",
-                    "-ffp-contract=off", "-fPIC", "-shared", "-DPSD_SPIN_STATS",
+    subprocess.run([entry.HIPCC] + entry.HIP_FLAGS + [ "-DPSD_SPIN_STATS",
                     "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
                     os.path.join(csrc, "peakseg_hip.cpp"), "-o", lib_path], check=True)
     lib = _native.declare(ctypes.CDLL(lib_path))

@@ -31,8 +31,8 @@ def main():
     os.makedirs(out, exist_ok=True)
     lib_path = os.path.join(out, "libpeaksegdisk_hip_prof.so")
     csrc = os.path.join(ROOT, "peaksegdisk_amd", "csrc")
-    subprocess.run(["/opt/rocm/bin/hipcc", "-x", "hip", "--offload-arch=gfx950", "-O3",
-                    "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DPSD_PROFILE"]
+    import __graft_entry__ as entry
+    subprocess.run([entry.HIPCC] + entry.HIP_FLAGS + ["-DPSD_PROFILE"]
                    + os.environ.get("PSD_PROFILE_FLAGS", "").split() + [
                     "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
                     os.path.join(csrc, "peakseg_hip.cpp"), "-o", lib_path], check=True)
