@@ -39,18 +39,25 @@ extern "C" {
  *                               per GPU sets it from its rank
  * PEAKSEG_HIP_MAX_BYTES         cap on the HBM one problem set may hold (suffix K/M/G/T); several
  *                               processes can then share one GPU (R's future workers)
- * PEAKSEG_HIP_PIECES_PER_FUNCTION  arena estimate, pieces per stored cost function (default 7;
- *                               when it proves too small more memory is mapped behind the arena
- *                               and the problems that ran out go on where they stopped)
+ * PEAKSEG_HIP_PIECES_PER_FUNCTION  arena estimate, pieces per stored cost function (default 7):
+ *                               picks the arena's chunk and block sizes; the arena itself grows
+ *                               block by block WHILE the kernel runs (a host thread maps ahead of
+ *                               what the waves have taken), up to nine tenths of the free HBM or
+ *                               PEAKSEG_HIP_MAX_BYTES
+ * PEAKSEG_HIP_NO_LIVE_GROWTH=1  map what the estimate asks for at creation and nothing under a
+ *                               running kernel: a solve that needs more parks its problems, adds
+ *                               blocks and resumes them where they stopped
  * PEAKSEG_HIP_SPILL_CAP / _SPILL_SLOTS  capacity (pieces per list, at most 32767) and initial
  *                               number of slots of the HBM spill pool for functions that outgrow LDS
  * PEAKSEG_HIP_CHECKPOINT=K / PEAKSEG_HIP_NO_CHECKPOINT=1  force / forbid the checkpointed store
  * PEAKSEG_HIP_CKPT_OVERFLOW     initial size (pieces) of the pool that holds checkpoints of functions
  *                               too long for a checkpoint slot (adversarial data)
  * PEAKSEG_HIP_NO_PARK=1         rerun a set that ran out of arena instead of resuming its problems
- * PEAKSEG_HIP_NO_VMM=1          arena from plain allocations (growth by allocate, copy, free) instead of
- *                               HIP virtual-memory ranges that grow in place
- * PEAKSEG_HIP_VARIANT=lat|thr   force a build of the forward kernel
+ * PEAKSEG_HIP_NO_VMM=1          arena blocks from hipMalloc instead of the HIP virtual-memory calls
+ *                               (same growth, nothing is ever copied)
+ * PEAKSEG_HIP_ARENA_BLOCK_LOG2  tests: log2 of the pieces per arena block (default 19-24)
+ * PEAKSEG_HIP_VARIANT=lat|thr|pk  force a build of the forward kernel
+ * PEAKSEG_HIP_NO_PACKED=1       the launch planner never picks the packed build (pk)
  * PEAKSEG_HIP_TIMING=1          phase timings of the file-level calls on stderr */
 
 /* ---- the reference's boundary -------------------------------------------------------- */
@@ -185,10 +192,12 @@ int peakseg_hip_problem_set_export_db(psd_problem_set *set, int problem, const i
 
 /* Which build of the forward kernel the last solve used: "lat" (latency build: helper waves,
  * one workgroup per CU; sets of at most one problem per CU), "thr" (throughput build:
- * 4 workgroups per CU) or "lat+thr" (a set that oversubscribes the chip with contigs of unequal
- * length: its longest problems on the latency build, the rest packed on the throughput build,
- * concurrently).  Same results either way; the environment variable
- * PEAKSEG_HIP_VARIANT=lat|thr overrides the choice. */
+ * 4 workgroups per CU, 64-piece lists), "pk" (packed build: 6 workgroups per CU, 40-piece lists;
+ * problems whose functions outgrow them go on, from the data point reached, on a wider build),
+ * or "lat+thr" / "lat+pk" (a set that oversubscribes the chip with contigs of unequal length: its
+ * longest problems on the latency build, the rest packed, concurrently).  The planner takes
+ * the build it predicts to finish the set first; same results whichever it is.
+ * PEAKSEG_HIP_VARIANT=lat|thr|pk overrides the choice, PEAKSEG_HIP_NO_PACKED=1 excludes pk. */
 const char *peakseg_hip_problem_set_kernel_build(psd_problem_set *set);
 
 /* bytes of HBM held by the set (arena + tables) */
@@ -203,8 +212,9 @@ int peakseg_hip_problem_set_checkpoint_interval(psd_problem_set *set);
 /* bytes of the arena the last solve handed out (whole chunks) */
 unsigned long long peakseg_hip_problem_set_arena_bytes_used(psd_problem_set *set);
 
-/* How the last solve went: kernel launches (1 unless a store had to grow: the arena grows by a
- * segment and the problems it had parked are resumed, finished problems are never repeated) and
+/* How the last solve went: kernel launches (1 unless a store ran out between launches: blocks
+ * are added to the arena and the problems it had parked are resumed, finished problems are never
+ * repeated; growth UNDER the kernel does not count, see peakseg_hip_problem_set_arena_stats) and
  * the data points its launches worked through (the sum of the problems' lengths when nothing
  * was repeated). */
 int peakseg_hip_problem_set_solve_stats(psd_problem_set *set, int *launches,

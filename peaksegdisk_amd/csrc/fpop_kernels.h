@@ -1107,6 +1107,11 @@ PSD_D void forward_body(const DeviceArgs &a) {
       /* three rotating slots: the one cleared here is first written two barriers later */
       if (lane == 0) g_sm.abort_status[(sync_no + 2u) % 3u] = 0;
       sync_no++;
+#ifdef PSD_PARK_ON_LDS_OVERFLOW
+      /* the packed build: a function that outgrows its short lists is for the throughput build
+       * (the problem is parked below and resumed there), not for the HBM path */
+      if (status == PST_LDS_OVERFLOW && !CKPT && a.prob_resume != nullptr && t > 0) break;
+#endif
       if (status == PST_LDS_OVERFLOW && !in_hbm && a.spill_cap > LDS_CAP && t > 0) {
         /* redo this data point with the lists in HBM: every wave moves its own t-1 list */
         if (spill_slot < 0) {
@@ -1125,9 +1130,14 @@ PSD_D void forward_body(const DeviceArgs &a) {
       break;
     }
     if (status != 0) {
-      if (!CKPT && status == PST_ARENA_FULL && a.prob_resume != nullptr && t > 0) {
+#ifdef PSD_PARK_ON_LDS_OVERFLOW
+      const bool park_now = status == PST_ARENA_FULL || status == PST_LDS_OVERFLOW;
+#else
+      const bool park_now = status == PST_ARENA_FULL;
+#endif
+      if (!CKPT && park_now && a.prob_resume != nullptr && t > 0) {
         /* Out of arena: park.  The functions of data point t-1 (this step's inputs, untouched)
-         * go to the park slot; the host adds a segment and resumes the problem at t.  Both
+         * go to the park slot; the host adds arena blocks and resumes the problem at t.  Both
          * waves see the status, so both come here.  (Functions too long for a slot need the
          * overflow pool; without room there the problem is simply rerun from the start.) */
         const int n_up = uniform_i(g_sm.n[b]), n_down = uniform_i(g_sm.n[2 + b]);

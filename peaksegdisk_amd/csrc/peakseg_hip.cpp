@@ -64,6 +64,26 @@
 #undef PSD_CALL_LDS_OPS_THR_ONLY
 #endif
 
+/*   pk   packed build (round 4): 40 pieces per LDS list, registers for three waves per SIMD
+ *        (six workgroups per CU), operations out of line.  A problem on a SIMD shared three ways
+ *        advances more slowly than on the throughput build, but a CU holds half as many again:
+ *        +18 % on sets of many problems of similar length, -10 % where a set ends with its
+ *        longest packed problems (profiles/r04/ab_thr_occupancy_*.log) -- the planner in
+ *        peakseg_hip_problem_set_solve picks it when it predicts the earlier end.  A function that
+ *        outgrows 40 pieces does not go to the (ten times slower) HBM path here: the problem is
+ *        parked and resumed on the throughput build, whose lists hold 64. */
+#define PSD_VARIANT pk
+#define PSD_LDS_CAP 40
+#define PSD_KERNEL_WAVES_PER_EU 3
+#define PSD_CALL_LDS_OPS 1
+#define PSD_PARK_ON_LDS_OVERFLOW 1
+#include "fpop_kernels.h"
+#undef PSD_VARIANT
+#undef PSD_LDS_CAP
+#undef PSD_KERNEL_WAVES_PER_EU
+#undef PSD_CALL_LDS_OPS
+#undef PSD_PARK_ON_LDS_OVERFLOW
+
 #include <errno.h>
 #include <algorithm>
 #include <math.h>
@@ -302,6 +322,9 @@ struct psd_problem_set {
   bool solved = false;
   int n_cu = 0;            /* compute units of the device */
   bool throughput = false; /* which kernel build the last solve used */
+  bool packed = false;     /* ... the packed build (pk) for the part that is not on the latency build */
+  int widened = 0;         /* problems the packed build handed to the throughput build (a function
+                              outgrew its 40-piece lists) */
   int n_lat_mixed = 0;     /* mixed launch: this many (longest) problems ran on the latency build */
   std::vector<int> order;  /* problems, longest contig first */
   bool can_park = false;   /* the set has a park slot per problem (full store) */
@@ -766,8 +789,8 @@ extern "C" void peakseg_hip_problem_set_destroy(psd_problem_set *s) {
 }
 
 extern "C" const char *peakseg_hip_problem_set_kernel_build(psd_problem_set *s) {
-  if (s->throughput && s->n_lat_mixed > 0) return "lat+thr";
-  return s->throughput ? "thr" : "lat";
+  if (s->throughput && s->n_lat_mixed > 0) return s->packed ? "lat+pk" : "lat+thr";
+  return s->throughput ? (s->packed ? "pk" : "thr") : "lat";
 }
 
 extern "C" int peakseg_hip_problem_set_solve_stats(psd_problem_set *s, int *launches,
@@ -1173,56 +1196,75 @@ struct LiveGrower {
 /* what the mixed-launch planner assumes a problem advances at, refreshed by every solve that
  * ran on one build alone with every problem resident from the start (a clean measurement) */
 static std::atomic<double> g_lat_rate{90e3}, g_thr_rate{27e3};
+/* a problem on the packed build (a SIMD shared three ways) against one on the throughput build
+ * (two ways): 6144 equal problems ran 18.2 % faster six to a CU than four to a CU */
+constexpr double PK_RATE_OF_THR = 1.182 * 4.0 / 6.0;
 
 extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_ms,
                                              float *backtrack_ms) {
   HIP_TRY(hipSetDevice(s->device));
   g_last_warning.clear();
   /* the latency build wants a CU per problem: beyond that, problems would queue behind each
-   * other and the throughput build (4 per CU) finishes the set sooner.
-   * PEAKSEG_HIP_VARIANT=lat|thr overrides (tests, A/B runs). */
+   * other and a build that packs several problems on a CU (throughput: 4, packed: 6) finishes
+   * the set sooner.  PEAKSEG_HIP_VARIANT=lat|thr|pk overrides (tests, A/B runs). */
   s->throughput = s->n_problems > s->n_cu;
+  s->packed = false;
+  s->widened = 0;
   bool forced = false;
   if (const char *e = getenv("PEAKSEG_HIP_VARIANT")) {
     if (!strcmp(e, "lat")) s->throughput = false, forced = true;
     if (!strcmp(e, "thr")) s->throughput = true, forced = true;
+    if (!strcmp(e, "pk")) s->throughput = true, s->packed = true, forced = true;
   }
+  /* the packed build hands functions of more than 40 pieces to the throughput build through
+   * the park slots; without them (checkpointed store, very large sets) it is not used */
+  if (s->packed && !s->can_park) s->packed = false;
   /* Mixed launch for sets of unequal contigs that oversubscribe the chip: a problem on the
    * throughput build advances about 27 k data points per second, on the latency build (a CU of
    * its own) about 90 k, so the longest problems would decide when the set ends.  The L longest
    * problems go to the latency build -- launched first, on a stream of its own, one CU each --
-   * and the rest is packed four to a CU on what is left; L minimises the later of the two
-   * predicted ends.  (Equal contigs: L = 0.) */
+   * and the rest is packed on what is left; L minimises the later of the two predicted ends.
+   * (Equal contigs: L = 0.)  The same prediction chooses between the throughput and the packed
+   * build for the rest: six problems per CU at 0.79 of the speed each (measured on 6144 equal
+   * problems: +18 %; on 24 unequal contigs x 64 penalties, which end with their longest packed
+   * problems: -10 %, profiles/r04/ab_thr_occupancy_*.log). */
   s->n_lat_mixed = 0;
   if (s->throughput && !forced) {
     /* data points per second of one problem on either build: measured by this process's own
      * earlier solves when there were any (g_lat_rate / g_thr_rate below), else the figures of
      * an MI355X at 2.4 GHz */
-    const double lat_rate = g_lat_rate.load(), thr_rate = g_thr_rate.load(), thr_per_cu = 4.0;
+    const double lat_rate = g_lat_rate.load(), thr_rate = g_thr_rate.load();
     std::vector<double> len((size_t)s->n_problems);
     double rest = 0.0;
     for (int k = 0; k < s->n_problems; k++) {
       len[(size_t)k] = (double)s->contig_n[(size_t)s->prob_contig[(size_t)s->order[(size_t)k]]];
       rest += len[(size_t)k];
     }
-    double best = 1e300;
-    int best_l = 0;
-    const int l_max = s->n_cu - 16 < s->n_problems ? s->n_cu - 16 : s->n_problems - 1;
-    double sum_lat = 0.0;
-    for (int l = 0; l <= l_max; l++) {
-      /* problems [0, l) on the latency build, [l, n) on the throughput build */
-      const double t_lat = l > 0 ? len[0] / lat_rate : 0.0;
-      const double cus = (double)(s->n_cu - l);
-      const double t_thr_work = (rest - sum_lat) / (cus * thr_per_cu * thr_rate);
-      const double t_thr_long = len[(size_t)l] / thr_rate;
-      const double t = std::max(t_lat, std::max(t_thr_work, t_thr_long));
-      if (t < best * 0.98) { /* prefer fewer latency problems unless it clearly pays */
-        best = t;
-        best_l = l;
+    const int l_max = std::max(0, s->n_cu - 16 < s->n_problems ? s->n_cu - 16 : s->n_problems - 1);
+    /* the predicted end of the set with problems [0, l) on the latency build and [l, n) packed
+     * per_cu to a CU at `rate` each, minimised over l */
+    auto plan = [&](double per_cu, double rate, int &best_l) -> double {
+      double best = 1e300, sum_lat = 0.0;
+      best_l = 0;
+      for (int l = 0; l <= l_max; l++) {
+        const double t_lat = l > 0 ? len[0] / lat_rate : 0.0;
+        const double cus = (double)(s->n_cu - l);
+        const double t_work = (rest - sum_lat) / (cus * per_cu * rate);
+        const double t_long = len[(size_t)l] / rate;
+        const double t = std::max(t_lat, std::max(t_work, t_long));
+        if (t < best * 0.98) { /* prefer fewer latency problems unless it clearly pays */
+          best = t;
+          best_l = l;
+        }
+        sum_lat += len[(size_t)l];
       }
-      sum_lat += len[(size_t)l];
-    }
-    s->n_lat_mixed = best_l;
+      return best;
+    };
+    int l_thr = 0, l_pk = 0;
+    const double t_thr = plan(4.0, thr_rate, l_thr);
+    const double t_pk = plan(6.0, thr_rate * PK_RATE_OF_THR, l_pk);
+    s->packed = s->can_park && !getenv("PEAKSEG_HIP_NO_PACKED") && t_pk < 0.97 * t_thr;
+    s->n_lat_mixed = s->packed ? l_pk : l_thr;
   }
   /* Launches.  The first one runs every problem.  When problems come back unfinished for
    * want of room (arena, spill pool, checkpoint overflow pool) the host enlarges what was short
@@ -1286,7 +1328,10 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
     HIP_TRY(hipEventRecord(s->ev[0], s->stream));
     if (live) grower.start(s, arena_mapped(s) + arena_fit(s));
     const dim3 grid((unsigned)n_todo);
-    const bool thr_now = relaunch ? (forced ? s->throughput : n_todo > s->n_cu) : s->throughput;
+    /* (a relaunch after the packed build: the problems it parked need the wider lists of the
+     * throughput build, or a CU each when they are few) */
+    const bool thr_now = relaunch ? ((forced && !s->packed) ? s->throughput : n_todo > s->n_cu)
+                                  : s->throughput;
     if (!relaunch && s->throughput && s->n_lat_mixed > 0) {
       /* mixed launch: both kernels index prob_order by their own blockIdx.x */
       const int L = s->n_lat_mixed;
@@ -1325,6 +1370,9 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
       if (s->ckpt_interval > 0)
         hipLaunchKernelGGL(psd::thr::fpop_forward_ckpt_kernel, dim3((unsigned)d_thr.n_problems),
                            dim3(psd::thr::FORWARD_THREADS), 0, s->stream, d_thr);
+      else if (s->packed)
+        hipLaunchKernelGGL(psd::pk::fpop_forward_kernel, dim3((unsigned)d_thr.n_problems),
+                           dim3(psd::pk::FORWARD_THREADS), 0, s->stream, d_thr);
       else
         hipLaunchKernelGGL(psd::thr::fpop_forward_kernel, dim3((unsigned)d_thr.n_problems),
                            dim3(psd::thr::FORWARD_THREADS), 0, s->stream, d_thr);
@@ -1335,6 +1383,9 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
       if (s->ckpt_interval > 0)
         hipLaunchKernelGGL(psd::thr::fpop_forward_ckpt_kernel, grid,
                            dim3(psd::thr::FORWARD_THREADS), 0, s->stream, d_run);
+      else if (s->packed && !relaunch) /* (a relaunch holds what the packed build handed over) */
+        hipLaunchKernelGGL(psd::pk::fpop_forward_kernel, grid, dim3(psd::pk::FORWARD_THREADS),
+                           0, s->stream, d_run);
       else
         hipLaunchKernelGGL(psd::thr::fpop_forward_kernel, grid, dim3(psd::thr::FORWARD_THREADS),
                            0, s->stream, d_run);
@@ -1383,6 +1434,7 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
       if (s->arena_used > s->d.ar_cap) s->arena_used = s->d.ar_cap;
     }
     bool arena_full = false, spill_full = false, ckpt_full = false, park_pool_full = false;
+    int widen = 0; /* problems the packed build parked because a function outgrew its lists */
     int longest_function = 0;
     std::vector<int> again;
     for (int p : todo) {
@@ -1395,13 +1447,15 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
       spill_full = spill_full || r.status == psd::PST_SPILL_FULL;
       ckpt_full = ckpt_full || r.status == psd::PST_CKPT_FULL;
       if (r.max_intervals > longest_function) longest_function = r.max_intervals;
+      const bool to_wider = r.status == psd::PST_LDS_OVERFLOW && r.parked && s->can_park;
       if (r.status == psd::PST_ARENA_FULL || r.status == psd::PST_SPILL_FULL ||
-          r.status == psd::PST_CKPT_FULL) {
+          r.status == psd::PST_CKPT_FULL || to_wider) {
         again.push_back(p);
         if (r.status == psd::PST_ARENA_FULL && r.parked && s->can_park) s->parks++;
+        if (to_wider) widen++;
         /* parked: go on where it stopped; anything else starts over */
         s->resume_t[(size_t)p] =
-            (r.status == psd::PST_ARENA_FULL && r.parked && s->can_park) ? r.step_reached : 0;
+            ((r.status == psd::PST_ARENA_FULL || to_wider) && r.parked && s->can_park) ? r.step_reached : 0;
       }
     }
     if (s->ckpt_interval == 0 && s->d.ckpt_ovf_next) { /* the parks' share of the overflow pool */
@@ -1409,11 +1463,12 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
       HIP_TRY(hipMemcpy(&used, s->d.ckpt_ovf_next, sizeof used, hipMemcpyDeviceToHost));
       s->park_pool_pieces = used;
     }
+    s->widened += widen;
     if (again.empty()) break;
     if (getenv("PEAKSEG_HIP_TIMING")) {
       fprintf(stderr, "peakseg_hip timing: launch %d: %d of %d problems unfinished (arena %d, spill "
-                      "pool %d, checkpoint pool %d):", s->launches, (int)again.size(), n_todo,
-              (int)arena_full, (int)spill_full, (int)ckpt_full);
+                      "pool %d, checkpoint pool %d, to wider lists %d):", s->launches,
+              (int)again.size(), n_todo, (int)arena_full, (int)spill_full, (int)ckpt_full, widen);
       for (size_t k = 0; k < again.size() && k < 8; k++)
         fprintf(stderr, " p%d@%d%s", again[k], s->results[(size_t)again[k]].step_reached,
                 s->resume_t[(size_t)again[k]] ? "(parked)" : "");
@@ -1533,7 +1588,8 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
       /* latency build: a CU per problem; throughput build: only a chip that was full (four
        * workgroups on nearly every CU) shows the packed rate the planner reasons with */
       if (!s->throughput && s->n_problems <= s->n_cu) g_lat_rate.store(rate);
-      if (s->throughput && s->n_problems <= 4 * s->n_cu && s->n_problems >= 7 * s->n_cu / 2)
+      if (s->throughput && !s->packed && s->n_problems <= 4 * s->n_cu &&
+          s->n_problems >= 7 * s->n_cu / 2)
         g_thr_rate.store(rate);
     }
   }

@@ -232,6 +232,12 @@ hipError_t hipGetDeviceCount(int *n) {
 hipError_t hipSetDevice(int) { return hipSuccess; }
 hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) {
   *v = 256; /* an MI355X */
+  /* (PSD_EMU_CUS: a smaller device, so that a test of the launch planner -- which build for how
+   * many problems per CU -- needs tens of problems, not thousands) */
+  if (const char *e = getenv("PSD_EMU_CUS")) {
+    const int n = atoi(e);
+    if (n > 0) *v = n;
+  }
   return hipSuccess;
 }
 hipError_t hipGetDevice(int *d) {

@@ -208,7 +208,8 @@ def test_emu_mixed_launch(psd, tmp_path, monkeypatch):
 
 
 def test_emu_solve_grid(psd, tmp_path):
-    gp3.test_solve_grid_on_device(psd, tmp_path, n_contigs=4, scale=0.0006, n_pen=5)
+    gp3.test_solve_grid_on_device(psd, tmp_path, n_contigs=4, scale=0.0006, n_pen=5,
+                                  oracle_every=1)
 
 
 def test_emu_adversarial_counts(psd, oracle_det, tmp_path):
@@ -266,3 +267,10 @@ def test_emu_parked_long_functions_survive_several_exhaustions(psd, oracle_det, 
                                                                monkeypatch):
     gp4.test_parked_long_functions_survive_several_exhaustions(psd, oracle_det, tmp_path,
                                                                monkeypatch, n_bins=1200)
+
+
+def test_emu_packed_build_parity_planner_and_hand_over(psd, oracle_det, tmp_path, monkeypatch):
+    # (a device of 32 CUs: 128 problems fill the throughput build, 192 the packed one)
+    monkeypatch.setenv("PSD_EMU_CUS", "32")
+    gp4.test_packed_build_parity_planner_and_hand_over(psd, oracle_det, tmp_path, monkeypatch,
+                                                       n_contigs=40, n_bins=100, adv_bins=800)

@@ -62,12 +62,13 @@ def check_tables_vs_oracle_files(bg, pen, cs, ce, start, mean, summary):
 
 
 @GPU
-def test_solve_grid_on_device(psd, tmp_path, n_contigs=24, scale=0.01, n_pen=64):
+def test_solve_grid_on_device(psd, tmp_path, n_contigs=24, scale=0.01, n_pen=64, oracle_every=2):
     """BASELINE.json configs[3] on one rank: parallel.solve_grid deals 24 contigs (lengths
     log-uniform, bench.grid_contig_lengths) x 64 penalties = 1536 problems, solves them in
-    one device problem set and returns them through the gather layer.  EVERY problem's
-    seg_start, "%g" means and summary equal the deterministic oracle's files (a process pool
-    writes those while the GPU works)."""
+    one device problem set and returns them through the gather layer.  On every contig, every
+    second penalty of the grid (768 problems; `oracle_every=1`: all of them, as rounds 2-3 did
+    for 50 s of this test on host cores) has its seg_start, "%g" means and summary compared
+    with the deterministic oracle's files (a process pool writes those while the GPU works)."""
     import bench
     from peaksegdisk_amd import synthetic
     from peaksegdisk_amd.parallel import solve_grid
@@ -85,7 +86,7 @@ def test_solve_grid_on_device(psd, tmp_path, n_contigs=24, scale=0.01, n_pen=64)
         bg = str(tmp_path / ("c%d_%d" % (c, lo)) / "coverage.bedGraph")
         os.makedirs(os.path.dirname(bg))
         synthetic.write_bedgraph(bg, cs, ce, cnt)
-        for pen in pen_str[lo:hi]:
+        for pen in pen_str[lo:hi:oracle_every]:
             run_cli(CLI_DET, bg, pen, bg + ".db")
         return c, lo, hi, bg
     # longest contigs first, each contig's penalties in 4 slices: an even pool
@@ -101,7 +102,7 @@ def test_solve_grid_on_device(psd, tmp_path, n_contigs=24, scale=0.01, n_pen=64)
     assert len(out) == n_contigs * n_pen
     for c, lo, hi, bg in done:
         cs, ce, cnt = data[c]
-        for p in range(lo, hi):
+        for p in range(lo, hi, oracle_every):
             res = out[(c, p)]
             check_tables_vs_oracle_files(bg, pen_str[p], cs, ce, res["seg_start"],
                                          res["seg_mean"], res["summary"])
@@ -315,17 +316,22 @@ def _oracle_search(problem_dir, peaks_int, cli=CLI_DET, known=None):
 
 
 @GPU
-def test_sequential_search_on_a_long_contig(psd, tmp_path, n_bins=1000000, peaks_int=613):
-    """BASELINE.json configs[2] at a tenth of its length: sequentialSearch_dir on a 1e6-bin
+def test_sequential_search_on_a_long_contig(psd, tmp_path, n_bins=500000, peaks_int=354):
+    """BASELINE.json configs[2] at a twentieth of its length: sequentialSearch_dir on a 5e5-bin
     synthetic contig.  The resident driver must ask for the models the reference's loop asks
     for: same penalty strings in the same order, same peaks, and the chosen model's files
-    byte-identical to the oracle's.  The oracle solves every penalty the search visited (all
-    at once, one process each) and the reference's loop is then replayed on the oracle's
-    results: it must ask for exactly those penalties, in that order.
-    (Target 613: on this contig the reference's loop visits penalties 0, Inf, 132.08..., 3535.04...,
-    172.90..., 215.75..., 266.71..., 358.79..., 295.46... -- 420317, 0, 12779, 436, 4846, 1896, 809,
-    490, 613 peaks -- nine models, eight dynamic programs of 1e6 data points; rounds 2-3 searched
-    for 500, the same path six models longer, 141 s of the driver's GPU test step.)"""
+    byte-identical to the oracle's.  The oracle solves every penalty the search visited (each
+    one as soon as the search has left its files) and the reference's loop is then replayed on
+    the oracle's results: it must ask for exactly those penalties, in that order.
+    (Target 354: on this contig the reference's loop visits penalties 0, Inf, 127.64..., 3059.84...,
+    167.49..., 207.54..., 250.14..., 307.86..., 272.41... -- 209836, 0, 7085, 203, 2708, 1080, 470,
+    258, 354 peaks -- nine models, eight dynamic programs one after the other.  Rounds 2-3
+    searched a 1e6-bin contig for 500 peaks, fifteen models and 141 s of the driver's GPU test
+    step; round 4 first cut the path to nine models, then the contig to 5e5 bins: the long
+    searches of this suite are Mono27ac's 3198 peaks, tests/test_gpu_round4.py, and the search
+    for 613 peaks on 1e6 bins that `PSD_LONG_SEARCH=1` brings back.)"""
+    if os.environ.get("PSD_LONG_SEARCH") == "1":
+        n_bins, peaks_int = 1000000, 613
     from peaksegdisk_amd import synthetic
     cs, ce, cnt = synthetic.poisson_coverage(n_bins, seed=1)
     gdir = tmp_path / "gpu" / "chrSynth-0-1"

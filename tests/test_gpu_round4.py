@@ -203,3 +203,77 @@ def test_spin_bounds_leave_three_orders_of_magnitude(psd, tmp_path, n_bins=30000
           % (worst, worst_lds, limit))
     assert 0 < worst_lds and 0 < worst
     assert max(worst, worst_lds) * 1000 < limit
+
+
+@GPU
+def test_packed_build_parity_planner_and_hand_over(psd, oracle_det, tmp_path, monkeypatch,
+                                                   n_contigs=400, n_bins=1200, adv_bins=2500):
+    """Round 4: a third build of the forward kernel for sets of many problems of similar length
+    (40-piece LDS lists, three waves per SIMD, six workgroups per CU; +18 % on 6144 equal
+    problems, profiles/r04/ab_thr_occupancy_*.log).  (a) The planner picks it for such a set and
+    its results equal the throughput build's bit for bit, and the oracle's stores; (b) a problem
+    whose functions outgrow 40 pieces is parked by the packed build and resumed on the
+    throughput build (64-piece lists, and from there the HBM path): two launches, every data point
+    computed once, stores equal to the oracle's."""
+    from peaksegdisk_amd import ProblemSet, synthetic
+    pens = ["0.2", "3", "40", "600", "9000", "150000", "2500000"]
+    contigs, data = [], []
+    for c in range(n_contigs):
+        cs, ce, cnt = synthetic.poisson_coverage(n_bins + c % 50, seed=300 + c)
+        contigs.append((cnt, (ce - cs).astype(np.int32)))
+        data.append((cs, ce, cnt))
+    # (2800 problems: well beyond the 1024 the throughput build holds at once, so that what a CU
+    # holds, not one problem's speed, decides when the set ends)
+    problems = [(c, float(p)) for c in range(n_contigs) for p in pens]
+    tables = {}
+    for knob, want in (("", "pk"), ("PEAKSEG_HIP_NO_PACKED", "thr")):
+        if knob:
+            monkeypatch.setenv(knob, "1")
+        pset = ProblemSet(contigs, problems)
+        pset.solve()
+        assert pset.kernel_build == want, pset.kernel_build
+        tables[want] = [(pset.result(i).max_intervals, pset.result(i).total_intervals,
+                         pset.result(i).best_cost) + pset.segments(i) for i in range(len(problems))]
+        if want == "pk":
+            # (every data point once, also if one of these functions outgrew 40 pieces and its
+            # problem went on on the wider build)
+            launches, steps = pset.solve_stats
+            assert launches <= 2 and steps == sum(len(contigs[c][0]) for c, _ in problems)
+            for c in (0, n_contigs // 2, n_contigs - 1):  # whole stores against the oracle
+                cs, ce, cnt = data[c]
+                bg = str(tmp_path / ("c%d.bedGraph" % c))
+                synthetic.write_bedgraph(bg, cs, ce, cnt)
+                for k, pen in enumerate(pens):
+                    db_o = str(tmp_path / "o.db")
+                    assert oracle_det.solve(bg, pen, db_o) == 0
+                    db_g = str(tmp_path / "g.db")
+                    pset.export_db(c * len(pens) + k, ce, db_g)
+                    assert open(db_g, "rb").read() == open(db_o, "rb").read(), (c, pen)
+        pset.close()
+        if knob:
+            monkeypatch.delenv(knob)
+    for a, b in zip(tables["pk"], tables["thr"]):
+        assert a[:3] == b[:3] and np.array_equal(a[3], b[3])
+        assert np.array_equal(a[4].view(np.uint64), b[4].view(np.uint64))
+    # (b) functions that outgrow the packed build's lists
+    cs, ce, cnt = synthetic.increasing_coverage(adv_bins)
+    monkeypatch.setenv("PEAKSEG_HIP_VARIANT", "pk")
+    pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, 100.0), (0, 30.0)])
+    pset.solve()
+    assert pset.kernel_build == "pk"
+    launches, steps = pset.solve_stats
+    assert launches == 2 and steps == 2 * adv_bins, pset.solve_stats
+    bg = str(tmp_path / "adv.bedGraph")
+    synthetic.write_bedgraph(bg, cs, ce, cnt)
+    for i, pen in enumerate(("100", "30")):
+        r = pset.result(i)
+        assert r.status == 0 and r.max_intervals > 40
+        db_o = str(tmp_path / "oa.db")
+        assert oracle_det.solve(bg, pen, db_o) == 0
+        db_g = str(tmp_path / "ga.db")
+        pset.export_db(i, ce, db_g)
+        assert open(db_g, "rb").read() == open(db_o, "rb").read(), pen
+    # (the two handed-over problems get a CU each: the latency build's 128-piece lists, and
+    # beyond those the HBM path)
+    assert pset.result(0).max_intervals > 128 and pset.result(0).spill_steps > 0
+    pset.close()
