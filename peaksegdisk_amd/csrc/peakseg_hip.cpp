@@ -1199,6 +1199,11 @@ static std::atomic<double> g_lat_rate{90e3}, g_thr_rate{27e3};
 /* a problem on the packed build (a SIMD shared three ways) against one on the throughput build
  * (two ways): 6144 equal problems ran 18.2 % faster six to a CU than four to a CU */
 constexpr double PK_RATE_OF_THR = 1.182 * 4.0 / 6.0;
+/* The planner cannot know how long a set's functions get.  When the packed build had to hand
+ * more than one problem in twenty to the wider builds (each of them waited for the end of the
+ * first launch before it went on), this process's later sets -- more of the same data, as a
+ * rule -- are planned without it. */
+static std::atomic<int> g_pk_handed_over_many{0};
 
 extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_ms,
                                              float *backtrack_ms) {
@@ -1263,7 +1268,8 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
     int l_thr = 0, l_pk = 0;
     const double t_thr = plan(4.0, thr_rate, l_thr);
     const double t_pk = plan(6.0, thr_rate * PK_RATE_OF_THR, l_pk);
-    s->packed = s->can_park && !getenv("PEAKSEG_HIP_NO_PACKED") && t_pk < 0.97 * t_thr;
+    s->packed = s->can_park && !getenv("PEAKSEG_HIP_NO_PACKED") &&
+                !g_pk_handed_over_many.load() && t_pk < 0.97 * t_thr;
     s->n_lat_mixed = s->packed ? l_pk : l_thr;
   }
   /* Launches.  The first one runs every problem.  When problems come back unfinished for
@@ -1573,6 +1579,8 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
     }
     todo.swap(again);
   }
+  if (s->packed && !forced && (long long)s->widened * 20 > (long long)s->n_problems)
+    g_pk_handed_over_many.store(1);
 #ifndef PSD_EMU /* (the emulator's timings say nothing about the hardware) */
   if (s->launches == 1 && s->n_lat_mixed == 0 && s->ckpt_interval == 0 && total_ms > 500.f) {
     /* a clean single launch: the longest problem's data points / kernel time is the rate of

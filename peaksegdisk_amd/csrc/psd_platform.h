@@ -19,7 +19,7 @@
 #define PSD_D static inline
 #define PSD_M inline
 #define PSD_NOINLINE static __attribute__((noinline))
-#define PSD_LDS static
+#define PSD_LDS static thread_local /* (a block per host thread at a time) */
 #define PSD_COLD_DEV static __attribute__((noinline, cold))
 #else
 #include <hip/hip_runtime.h>
@@ -120,7 +120,7 @@ PSD_D long long cycle_now() { return (long long)__builtin_readcyclecounter(); }
 PSD_D int flag_load(const int *p) { return *(const volatile int *)p; }
 PSD_D void flag_store(int *p, int v) { *(volatile int *)p = v; }
 PSD_D void spin_pause() { emu::yield_fiber(); }
-PSD_D void device_fence() {}
+PSD_D void device_fence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 #else
 PSD_D int flag_load(const int *p) {
   return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);

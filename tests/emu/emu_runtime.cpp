@@ -4,6 +4,8 @@
 #include <sys/mman.h>
 #include <time.h>
 
+#include <atomic>
+#include <thread>
 #include <vector>
 
 extern "C" void psd_emu_switch(void **save_sp, void *load_sp);
@@ -32,7 +34,7 @@ psd_emu_switch:
 
 namespace emu {
 
-ThreadCtx *g_cur = nullptr;
+thread_local ThreadCtx *g_cur = nullptr;
 
 namespace {
 
@@ -54,6 +56,10 @@ struct Fiber {
 };
 
 struct BlockState {
+  ~BlockState() {
+    for (Fiber &f : fibers)
+      if (f.stack) munmap(f.stack, STACK_BYTES);
+  }
   std::vector<Fiber> fibers;
   std::vector<Wave> waves;
   int bar_arrived = 0;
@@ -66,7 +72,7 @@ struct BlockState {
   unsigned nthreads = 0;
 };
 
-BlockState *g_blk = nullptr;
+thread_local BlockState *g_blk = nullptr;
 
 void yield_to_scheduler() {
   Fiber *f = g_blk->cur;
@@ -170,8 +176,10 @@ void syncthreads() {
   }
 }
 
-void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
-  static BlockState blk; /* stacks are reused across launches */
+/* the blocks [next, grid.x) of a launch, taken one at a time by the calling host thread */
+static void run_blocks(dim3 grid, dim3 block, const std::function<void()> &body,
+                       std::atomic<unsigned> &next) {
+  static thread_local BlockState blk; /* stacks are reused across the launches of a thread */
   unsigned nthreads = block.x;
   if (blk.fibers.size() < nthreads) blk.fibers.resize(nthreads);
   blk.waves.assign((nthreads + 63) / 64, Wave());
@@ -180,7 +188,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
   BlockState *saved_blk = g_blk;
   ThreadCtx *saved_cur = g_cur;
   g_blk = &blk;
-  for (unsigned b = 0; b < grid.x; b++) {
+  for (unsigned b = next.fetch_add(1); b < grid.x; b = next.fetch_add(1)) {
     for (auto &w : blk.waves) w = Wave();
     for (unsigned t = 0; t < nthreads; t++) {
       Fiber &f = blk.fibers[t];
@@ -215,6 +223,23 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
   }
   g_blk = saved_blk;
   g_cur = saved_cur;
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
+  /* Blocks are independent (they meet in global memory through atomics only, as on the
+   * device): a few host threads take them one at a time.  The calling thread is one of them,
+   * so a launch of one block runs exactly as it did when blocks ran one after another. */
+  unsigned workers = std::thread::hardware_concurrency();
+  if (workers > 8) workers = 8;
+  if (const char *e = getenv("PSD_EMU_THREADS")) workers = (unsigned)atoi(e);
+  if (workers < 1) workers = 1;
+  if (workers > grid.x) workers = grid.x;
+  std::atomic<unsigned> next{0};
+  std::vector<std::thread> pool;
+  for (unsigned w = 1; w < workers; w++)
+    pool.emplace_back([&]() { run_blocks(grid, block, body, next); });
+  run_blocks(grid, block, body, next);
+  for (auto &t : pool) t.join();
 }
 
 }  // namespace emu

@@ -2,7 +2,9 @@
  *
  * Lets the product's kernel source (peaksegdisk_amd/csrc/) be compiled by g++ and
  * run on the CPU so kernel *logic* can be debugged and parity-tested without a GPU.  Each
- * GPU thread is a fiber (hand-rolled x86-64 context switch); blocks run one after another;
+ * GPU thread is a fiber (hand-rolled x86-64 context switch); the blocks of a launch are dealt
+ * to a few host threads (PSD_EMU_THREADS, default: the cores, at most 8), each of which runs its
+ * blocks one after another with its own copy of every __shared__ variable (thread_local);
  * ballot/shfl/wave_sync and __syncthreads() are rendezvous points that every lane of the
  * wave (every thread of the block) must reach in the same order -- the discipline the
  * kernels follow on the real hardware too (psd_platform.h).
@@ -26,7 +28,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline
-#define __shared__ static
+#define __shared__ static thread_local
 #define __launch_bounds__(...)
 #ifndef __restrict__
 #define __restrict__
@@ -41,7 +43,7 @@ namespace emu {
 struct ThreadCtx {
   dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
 };
-extern ThreadCtx *g_cur;
+extern thread_local ThreadCtx *g_cur;
 unsigned long long ballot(bool p);
 double shfl_f64(double v, int src);
 int shfl_i32(int v, int src);
@@ -58,32 +60,24 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body);
 
 static inline void __syncthreads() { emu::syncthreads(); }
 
-/* fibers never run concurrently, so plain read-modify-write is atomic */
+/* (the fibers of a block never run concurrently, but blocks on other host threads do) */
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) {
-  unsigned long long o = *p;
-  *p = o + v;
-  return o;
+  return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST);
 }
 static inline unsigned int atomicAdd(unsigned int *p, unsigned int v) {
-  unsigned int o = *p;
-  *p = o + v;
-  return o;
+  return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST);
 }
-static inline int atomicAdd(int *p, int v) {
-  int o = *p;
-  *p = o + v;
-  return o;
-}
+static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 static inline int atomicAdd_system(int *p, int v) { return atomicAdd(p, v); }
 static inline int atomicMax(int *p, int v) {
-  int o = *p;
-  if (v > o) *p = v;
+  int o = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+  while (v > o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
+  }
   return o;
 }
 static inline int atomicCAS(int *p, int cmp, int v) {
-  int o = *p;
-  if (o == cmp) *p = v;
-  return o;
+  (void)__atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+  return cmp;
 }
 
 /* ---- host runtime subset ------------------------------------------------------------ */

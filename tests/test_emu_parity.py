@@ -273,4 +273,5 @@ def test_emu_packed_build_parity_planner_and_hand_over(psd, oracle_det, tmp_path
     # (a device of 32 CUs: 128 problems fill the throughput build, 192 the packed one)
     monkeypatch.setenv("PSD_EMU_CUS", "32")
     gp4.test_packed_build_parity_planner_and_hand_over(psd, oracle_det, tmp_path, monkeypatch,
-                                                       n_contigs=40, n_bins=100, adv_bins=800)
+                                                       n_contigs=40, n_bins=100, adv_bins=800,
+                                                       many=(270, 200))

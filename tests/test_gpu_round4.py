@@ -207,14 +207,16 @@ def test_spin_bounds_leave_three_orders_of_magnitude(psd, tmp_path, n_bins=30000
 
 @GPU
 def test_packed_build_parity_planner_and_hand_over(psd, oracle_det, tmp_path, monkeypatch,
-                                                   n_contigs=400, n_bins=1200, adv_bins=2500):
+                                                   n_contigs=400, n_bins=1200, adv_bins=2500,
+                                                   many=(2100, 300)):
     """Round 4: a third build of the forward kernel for sets of many problems of similar length
     (40-piece LDS lists, three waves per SIMD, six workgroups per CU; +18 % on 6144 equal
     problems, profiles/r04/ab_thr_occupancy_*.log).  (a) The planner picks it for such a set and
     its results equal the throughput build's bit for bit, and the oracle's stores; (b) a problem
     whose functions outgrow 40 pieces is parked by the packed build and resumed on the
     throughput build (64-piece lists, and from there the HBM path): two launches, every data point
-    computed once, stores equal to the oracle's."""
+    computed once, stores equal to the oracle's; (c) after a set that handed over many of its
+    problems, the planner leaves the packed build alone."""
     from peaksegdisk_amd import ProblemSet, synthetic
     pens = ["0.2", "3", "40", "600", "9000", "150000", "2500000"]
     contigs, data = [], []
@@ -276,4 +278,28 @@ def test_packed_build_parity_planner_and_hand_over(psd, oracle_det, tmp_path, mo
     # (the two handed-over problems get a CU each: the latency build's 128-piece lists, and
     # beyond those the HBM path)
     assert pset.result(0).max_intervals > 128 and pset.result(0).spill_steps > 0
+    pset.close()
+    monkeypatch.delenv("PEAKSEG_HIP_VARIANT")
+    # (c) the planner cannot know how long functions get: a set it gave to the packed build and
+    # that handed over more than one problem in twenty turns the packed build off for the sets
+    # this process plans afterwards
+    n_many, bins_many = many
+    cs, ce, cnt = synthetic.increasing_coverage(bins_many)
+    long_set = ([(cnt, (ce - cs).astype(np.int32))], [(0, 100.0)] * n_many)
+    pset = ProblemSet(*long_set)
+    pset.solve()
+    # (every problem is handed over here; those the park pool had no room for start over on the
+    # wider build, after the pool has grown)
+    assert pset.kernel_build == "pk"
+    assert pset.solve_stats[0] >= 2 and pset.solve_stats[1] >= n_many * bins_many
+    first = (pset.result(0).best_cost, pset.result(0).max_intervals) + pset.segments(0)
+    assert first[1] > 40
+    pset.close()
+    pset = ProblemSet(*long_set)
+    pset.solve()
+    assert pset.kernel_build == "thr"
+    again = (pset.result(n_many - 1).best_cost, pset.result(n_many - 1).max_intervals) \
+        + pset.segments(n_many - 1)
+    assert first[:2] == again[:2] and np.array_equal(first[2], again[2])
+    assert np.array_equal(first[3].view(np.uint64), again[3].view(np.uint64))
     pset.close()
