@@ -336,7 +336,7 @@ VARIED_SHAPES_RUN = (18, 2024)
 def test_varied_data_shapes(psd, oracle_det, tmp_path, monkeypatch, n_cases, seed):
     """Coverage that does not look like the Poisson generator: heavy tails, long zero runs,
     counts in the millions, smooth ramps, steps, 0/1 data, random bin widths and penalties
-    (0 included).  Both kernel builds; every stored function against the oracle's db."""
+    (0 included).  All three kernel builds; every stored function against the oracle's db."""
     from peaksegdisk_amd import ProblemSet, synthetic
     for case, (cnt, w, cs, ce, pens) in enumerate(varied_shape_cases(n_cases, seed)):
         bg = str(tmp_path / ("c%d.bedGraph" % case))
@@ -347,7 +347,7 @@ def test_varied_data_shapes(psd, oracle_det, tmp_path, monkeypatch, n_cases, see
             assert oracle_det.solve(bg, pen, db_o) == 0
             want.append(open(db_o, "rb").read())
             os.unlink(db_o)
-        for build in ("lat", "thr"):
+        for build in ("lat", "thr", "pk"):
             monkeypatch.setenv("PEAKSEG_HIP_VARIANT", build)
             pset = ProblemSet([(cnt, w.astype(np.int32))], [(0, float(p)) for p in pens])
             pset.solve()

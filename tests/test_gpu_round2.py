@@ -430,7 +430,7 @@ def test_newton_step_cap_fallback_on_device(psd, tmp_path):
         assert oracle100.solve(bg, pen, db100) == 0
         differs = differs or open(db100, "rb").read() != want[-1]
     assert differs, "cap of 5 steps did not change anything: fallback not exercised"
-    for build in ("lat", "thr"):
+    for build in ("lat", "thr", "pk"):
         os.environ["PEAKSEG_HIP_VARIANT"] = build
         try:
             pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, float(p)) for p in pens],
