@@ -991,8 +991,12 @@ PSD_D void forward_body(const DeviceArgs &a) {
       if (in_hbm) {
         spill_slot = uniform_i(take_spill_slot(*a.self, chain));
         if (spill_slot < 0) {
+          /* (the pool has no slot yet for these long functions: the park slot stays as it is
+           * and the problem resumes here again once the host has enlarged the pool) */
           status = PST_SPILL_FULL;
           resumed_abort = true;
+          parked = 1;
+          step_reached = t_resume;
         }
       }
       if (!resumed_abort) {
@@ -1130,13 +1134,17 @@ PSD_D void forward_body(const DeviceArgs &a) {
       break;
     }
     if (status != 0) {
+      /* (no spill slot: this data point's inputs are still in LDS -- the pool was needed for
+       * its result -- so the problem parks like one that ran out of arena and goes on at this
+       * data point when the host has enlarged the pool, instead of starting over) */
 #ifdef PSD_PARK_ON_LDS_OVERFLOW
-      const bool park_now = status == PST_ARENA_FULL || status == PST_LDS_OVERFLOW;
+      const bool park_now = status == PST_ARENA_FULL || status == PST_SPILL_FULL ||
+                            status == PST_LDS_OVERFLOW;
 #else
-      const bool park_now = status == PST_ARENA_FULL;
+      const bool park_now = status == PST_ARENA_FULL || status == PST_SPILL_FULL;
 #endif
       if (!CKPT && park_now && a.prob_resume != nullptr && t > 0) {
-        /* Out of arena: park.  The functions of data point t-1 (this step's inputs, untouched)
+        /* Out of arena (or of spill slots): park.  The functions of data point t-1 (this step's inputs, untouched)
          * go to the park slot; the host adds arena blocks and resumes the problem at t.  Both
          * waves see the status, so both come here.  (Functions too long for a slot need the
          * overflow pool; without room there the problem is simply rerun from the start.) */

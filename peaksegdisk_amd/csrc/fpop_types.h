@@ -31,7 +31,7 @@ enum {
   PST_ARENA_FULL = 2,    /* host retries with a larger arena */
   PST_REF_THROW = 3,     /* the reference would throw / loop / read a list sentinel */
   PST_BACKTRACK = 4,     /* findMean found no piece (the reference would never return) */
-  PST_SPILL_FULL = 5,    /* no free slot in the HBM spill pool: host retries with more slots */
+  PST_SPILL_FULL = 5,    /* no free slot in the HBM spill pool: parked; the host resumes it with more slots */
   PST_CKPT_SPILL = 6,    /* (rounds 1-2: a function to checkpoint had outgrown LDS; no longer raised) */
   PST_CKPT_FULL = 7,     /* checkpointed store: the overflow pool for checkpoints of functions with
                             more than ckpt_cap pieces is exhausted: host retries with a larger one */

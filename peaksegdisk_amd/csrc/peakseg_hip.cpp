@@ -1460,8 +1460,11 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
         if (r.status == psd::PST_ARENA_FULL && r.parked && s->can_park) s->parks++;
         if (to_wider) widen++;
         /* parked: go on where it stopped; anything else starts over */
-        s->resume_t[(size_t)p] =
-            ((r.status == psd::PST_ARENA_FULL || to_wider) && r.parked && s->can_park) ? r.step_reached : 0;
+        s->resume_t[(size_t)p] = ((r.status == psd::PST_ARENA_FULL || to_wider ||
+                                   r.status == psd::PST_SPILL_FULL) &&
+                                  r.parked && s->can_park)
+                                     ? r.step_reached
+                                     : 0;
       }
     }
     if (s->ckpt_interval == 0 && s->d.ckpt_ovf_next) { /* the parks' share of the overflow pool */
@@ -1565,10 +1568,14 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
           const double need = (double)s->arena_used / done * rest * 1.3 - left;
           if (need > (double)more) more = (unsigned long long)need;
         }
+        /* (at least four chunks for every problem that comes back: a set that ran out with
+         * all its problems nearly done estimates less than their next requests take) */
         const unsigned long long fit = arena_fit(s);
-        if (more > fit) more = fit;
         const unsigned long long chunk = 1ull << s->d.ar_chunk_log2;
-        if (more < chunk * 4ull * (unsigned long long)again.size()) {
+        const unsigned long long least = chunk * 4ull * (unsigned long long)again.size();
+        if (more < least) more = least;
+        if (more > fit) more = fit;
+        if (more < least) {
           set_error("cost-function arena cannot grow beyond %llu pieces (free HBM / "
                     "PEAKSEG_HIP_MAX_BYTES)", s->arena_pieces);
           return ERROR_DEVICE_MEMORY;

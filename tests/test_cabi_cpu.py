@@ -210,10 +210,12 @@ def test_fast_parser_equals_sscanf(native, tmp_path):
 
 
 def test_kernel_resource_budgets(tmp_path):
-    """The two builds of the forward kernel are defined by their occupancy:
-    the throughput build must fit 2 waves per SIMD and 4 workgroups per CU (<= 40 KB LDS) --
-    a register or LDS regression silently halves its throughput -- and the latency build must
-    fit one workgroup of 4 waves.  Checked on the compiler's resource remarks (no GPU needed)."""
+    """The builds of the forward kernel are defined by their occupancy (DESIGN.md sections 3, 8):
+    the throughput build must fit 2 waves per SIMD and 4 workgroups per CU (<= 40 KB LDS), the
+    packed build 3 waves per SIMD and 6 workgroups per CU (<= 26.6 KB) -- a register or LDS
+    regression silently costs a third to a half of their throughput -- and the latency build
+    must fit one workgroup of 4 waves.  Checked on the compiler's resource remarks (no GPU
+    needed)."""
     import re
     import subprocess
     import __graft_entry__ as entry
@@ -236,6 +238,9 @@ def test_kernel_resource_budgets(tmp_path):
                 info[name][key] = int(m.group(1))
     thr = next(v for k, v in info.items() if "3thr19fpop_forward_kernel" in k)
     lat = next(v for k, v in info.items() if "3lat19fpop_forward_kernel" in k)
+    pk = next(v for k, v in info.items() if "2pk19fpop_forward_kernel" in k)
+    assert pk["Occupancy [waves/SIMD]"] >= 3, pk
+    assert pk["LDS Size [bytes/block]"] <= 160 * 1024 // 6, pk
     assert thr["Occupancy [waves/SIMD]"] >= 2, thr
     assert thr["LDS Size [bytes/block]"] <= 40 * 1024, thr
     assert lat["Occupancy [waves/SIMD]"] >= 1 and lat["LDS Size [bytes/block]"] <= 160 * 1024, lat

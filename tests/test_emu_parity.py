@@ -275,3 +275,9 @@ def test_emu_packed_build_parity_planner_and_hand_over(psd, oracle_det, tmp_path
     gp4.test_packed_build_parity_planner_and_hand_over(psd, oracle_det, tmp_path, monkeypatch,
                                                        n_contigs=40, n_bins=100, adv_bins=800,
                                                        many=(270, 200))
+
+
+def test_emu_spill_pool_exhaustion_parks(psd, oracle_det, tmp_path, monkeypatch):
+    gp4.test_spill_pool_exhaustion_parks_instead_of_starting_over(psd, oracle_det, tmp_path,
+                                                                  monkeypatch, n_bins=800)
+

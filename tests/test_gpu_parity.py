@@ -251,7 +251,8 @@ def test_adversarial_increasing_counts_spill(psd, oracle_det, tmp_path, n_bins):
 @GPU
 @pytest.mark.parametrize("n_bins,n_contigs", [(3000, 72)])
 def test_throughput_build_identical(psd, oracle_det, tmp_path, monkeypatch, n_bins, n_contigs):
-    """The library carries two builds of the forward kernel (peakseg_hip.cpp): "lat" (helper
+    """The library carries three builds of the forward kernel (peakseg_hip.cpp; the third, "pk", has
+    its own test in test_gpu_round4.py): "lat" (helper
     waves, 128 pieces per LDS list) for sets that fit the chip at 2 workgroups per CU, "thr"
     (no helper waves, 64 pieces per LDS list, 4 workgroups per CU) beyond that.  Same results:
     a set large enough to pick "thr" by itself is compared with the same set forced onto

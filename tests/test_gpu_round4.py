@@ -303,3 +303,34 @@ def test_packed_build_parity_planner_and_hand_over(psd, oracle_det, tmp_path, mo
     assert first[:2] == again[:2] and np.array_equal(first[2], again[2])
     assert np.array_equal(first[3].view(np.uint64), again[3].view(np.uint64))
     pset.close()
+
+
+@GPU
+def test_spill_pool_exhaustion_parks_instead_of_starting_over(psd, oracle_det, tmp_path, monkeypatch,
+                                                              n_bins=2500, n_problems=6):
+    """Functions that outgrow the LDS lists move to a slot of the HBM spill pool; when more
+    problems need one at the same time than the pool has, rounds 1-3 started those problems
+    over after enlarging the pool.  Now they park at the data point that needed the slot (its
+    inputs are still in LDS) and go on from there: a pool of one slot and six problems that all
+    need it at the same data point take three launches (1, 4, 16 slots) and compute every data
+    point once; stores equal to the oracle's."""
+    from peaksegdisk_amd import ProblemSet, synthetic
+    cs, ce, cnt = synthetic.increasing_coverage(n_bins)
+    monkeypatch.setenv("PEAKSEG_HIP_SPILL_SLOTS", "1")
+    pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, 100.0)] * n_problems)
+    pset.solve()
+    launches, steps = pset.solve_stats
+    assert launches == 3 and steps == n_problems * n_bins, pset.solve_stats
+    bg = str(tmp_path / "adv.bedGraph")
+    synthetic.write_bedgraph(bg, cs, ce, cnt)
+    db_o = str(tmp_path / "o.db")
+    assert oracle_det.solve(bg, "100", db_o) == 0
+    want = open(db_o, "rb").read()
+    for i in range(n_problems):
+        r = pset.result(i)
+        assert r.status == 0 and r.spill_steps > 0
+        db_g = str(tmp_path / "g.db")
+        pset.export_db(i, ce, db_g)
+        assert open(db_g, "rb").read() == want, i
+    pset.close()
+

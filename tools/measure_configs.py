@@ -64,8 +64,9 @@ def c5(n=100000):
 def c3(n=2000000, peaks=300, seed=3, trace=None):
     """sequentialSearch_dir through the resident native driver.  trace: a log of the same search
     driven by the CPU oracle (tools: one dict per model, as profiles/r02/
-    config3_cpu_trace_1e7_det_oracle.log); the models visited must then equal its first ones,
-    penalty strings included."""
+    config3_cpu_trace_1e7_det_oracle.log -- which is the trace of `c3 10000000 3148 1`: SEED 1,
+    the bench's contig; with another seed the search never meets 3148 peaks and runs on); the
+    models visited must then equal its first ones, penalty strings included."""
     import ast
     import peaksegdisk_amd as psd
     from peaksegdisk_amd import synthetic
