@@ -737,6 +737,9 @@ int grow_ckpt_overflow_keep(psd_problem_set *s, unsigned long long pieces) {
    * are positions, not sizes, so the arrays are copied as they are */
   HIP_TRY(hipMemcpy(f64, s->d.ckpt_ovf_f64, old * 6 * sizeof(double), hipMemcpyDeviceToDevice));
   HIP_TRY(hipMemcpy(i32, s->d.ckpt_ovf_i32, old * sizeof(int), hipMemcpyDeviceToDevice));
+  /* (device-to-device copies may return before they have run, and the set's streams do not wait
+   * for the null stream) */
+  HIP_TRY(hipStreamSynchronize((hipStream_t) nullptr));
   free_ckpt_overflow(s);
   s->d.ckpt_ovf_f64 = f64;
   s->d.ckpt_ovf_i32 = i32;
@@ -823,8 +826,9 @@ extern "C" int peakseg_hip_problem_set_set_penalty(psd_problem_set *s, int p, do
   if (!s || p < 0 || p >= s->n_problems) return -1;
   if (hipSetDevice(s->device) != hipSuccess) return -1;
   s->prob_penalty[(size_t)p] = penalty;
-  if (hipMemcpy(const_cast<double *>(s->d.prob_penalty) + p, &penalty, sizeof(double),
-                hipMemcpyHostToDevice) != hipSuccess) {
+  if (hipMemcpyAsync(const_cast<double *>(s->d.prob_penalty) + p, &penalty, sizeof(double),
+                     hipMemcpyHostToDevice, s->stream) != hipSuccess ||
+      hipStreamSynchronize(s->stream) != hipSuccess) { /* (in order with the set's launches) */
     set_error("penalty upload failed");
     return -1;
   }
@@ -1135,6 +1139,15 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
     return ERROR_DEVICE_SOLVER;
   }
   s->results.resize((size_t)n_problems);
+  /* the set's streams do not synchronise with the null stream (hipStreamNonBlocking, so that
+   * arena blocks can be mapped under a running kernel): whatever the creation put on the null
+   * stream -- the memsets of the tables above may return before they have run -- is complete
+   * before a solve launches anything */
+  if ((e = hipStreamSynchronize((hipStream_t) nullptr)) != hipSuccess) {
+    set_error("creating the problem set: %s", hipGetErrorString(e));
+    peakseg_hip_problem_set_destroy(s);
+    return ERROR_DEVICE_SOLVER;
+  }
   lap("streams, events");
   *out = s;
   return 0;
