@@ -281,3 +281,8 @@ def test_emu_spill_pool_exhaustion_parks(psd, oracle_det, tmp_path, monkeypatch)
     gp4.test_spill_pool_exhaustion_parks_instead_of_starting_over(psd, oracle_det, tmp_path,
                                                                   monkeypatch, n_bins=800)
 
+
+def test_emu_knob_combinations_on_a_mixed_set(psd, oracle_det, tmp_path, monkeypatch):
+    gp4.test_knob_combinations_on_a_mixed_set(psd, oracle_det, tmp_path, monkeypatch,
+                                              n_poisson=600, n_increasing=500, n_shapes=2)
+

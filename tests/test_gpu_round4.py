@@ -334,3 +334,86 @@ def test_spill_pool_exhaustion_parks_instead_of_starting_over(psd, oracle_det, t
         assert open(db_g, "rb").read() == want, i
     pset.close()
 
+
+KNOB_COMBINATIONS = [
+    # packed build, everything that can run short runs short: hand-over to the wider builds,
+    # parks for want of arena (no growth under the kernel, tiny blocks) and of spill slots
+    {"PEAKSEG_HIP_VARIANT": "pk", "PEAKSEG_HIP_SPILL_SLOTS": "1", "PEAKSEG_HIP_PIECES_PER_FUNCTION": "1",
+     "PEAKSEG_HIP_NO_LIVE_GROWTH": "1", "PEAKSEG_HIP_ARENA_BLOCK_LOG2": "12"},
+    # throughput build, growth under the kernel with tiny blocks, one spill slot, a small pool
+    # for the parked long functions
+    {"PEAKSEG_HIP_VARIANT": "thr", "PEAKSEG_HIP_SPILL_SLOTS": "1", "PEAKSEG_HIP_PIECES_PER_FUNCTION": "1",
+     "PEAKSEG_HIP_ARENA_BLOCK_LOG2": "12", "PEAKSEG_HIP_CKPT_OVERFLOW": "256"},
+    # latency build on plain allocations, no growth under the kernel
+    {"PEAKSEG_HIP_VARIANT": "lat", "PEAKSEG_HIP_NO_VMM": "1", "PEAKSEG_HIP_SPILL_SLOTS": "1",
+     "PEAKSEG_HIP_PIECES_PER_FUNCTION": "1", "PEAKSEG_HIP_NO_LIVE_GROWTH": "1",
+     "PEAKSEG_HIP_ARENA_BLOCK_LOG2": "13", "PEAKSEG_HIP_CKPT_OVERFLOW": "256"},
+    # problems that cannot park (rounds 1-2): every exhaustion starts them over
+    {"PEAKSEG_HIP_VARIANT": "thr", "PEAKSEG_HIP_NO_PARK": "1", "PEAKSEG_HIP_SPILL_SLOTS": "1",
+     "PEAKSEG_HIP_PIECES_PER_FUNCTION": "1", "PEAKSEG_HIP_NO_LIVE_GROWTH": "1",
+     "PEAKSEG_HIP_ARENA_BLOCK_LOG2": "12"},
+    # the planner's own choice, growth under the kernel, defaults otherwise
+    {"PEAKSEG_HIP_SPILL_SLOTS": "2", "PEAKSEG_HIP_ARENA_BLOCK_LOG2": "12"},
+    # the checkpointed store (no parking there): one spill slot, a small pool for the
+    # checkpoints of long functions, on both builds it can run on
+    {"PEAKSEG_HIP_CHECKPOINT": "64", "PEAKSEG_HIP_VARIANT": "thr", "PEAKSEG_HIP_SPILL_SLOTS": "1",
+     "PEAKSEG_HIP_CKPT_OVERFLOW": "256", "PEAKSEG_HIP_ARENA_BLOCK_LOG2": "12"},
+    {"PEAKSEG_HIP_CHECKPOINT": "37", "PEAKSEG_HIP_VARIANT": "lat", "PEAKSEG_HIP_SPILL_SLOTS": "1",
+     "PEAKSEG_HIP_CKPT_OVERFLOW": "256"},
+]
+
+
+@GPU
+def test_knob_combinations_on_a_mixed_set(psd, oracle_det, tmp_path, monkeypatch, n_poisson=3000,
+                                          n_increasing=1200, n_shapes=3):
+    """The ways a solve can run short -- arena (with and without growth under the kernel), spill
+    slots, the pool for parked long functions, the packed build's lists -- were each tested on
+    data made for them.  Here they meet: one set of Poisson coverage, increasing counts (functions
+    of hundreds of pieces) and three of the odd data shapes, several penalties each, solved under
+    combinations of the knobs that make everything scarce at once.  Every problem of every
+    combination: status 0 and the whole store equal to the oracle's database (the checkpointed
+    store keeps no database: segment table and summary against the oracle's files)."""
+    from peaksegdisk_amd import ProblemSet, synthetic
+    from test_gpu_parity import varied_shape_cases
+    from test_gpu_round3 import check_tables_vs_oracle_files
+    data = []
+    cs, ce, cnt = synthetic.poisson_coverage(n_poisson, seed=77)
+    data.append((cnt, ce - cs, cs, ce, ["0.5", "40", "3000", "200000"]))
+    cs, ce, cnt = synthetic.increasing_coverage(n_increasing)
+    data.append((cnt, ce - cs, cs, ce, ["100", "30", "1000"]))
+    for cnt, w, cs, ce, pens in varied_shape_cases(n_shapes, 4242):
+        data.append((cnt, w, cs, ce, pens))
+    contigs = [(np.asarray(c).astype(np.int32), np.asarray(w).astype(np.int32)) for c, w, _, _, _ in data]
+    problems, want, files = [], [], []
+    for k, (cnt, w, cs, ce, pens) in enumerate(data):
+        bg = str(tmp_path / ("k%d.bedGraph" % k))
+        synthetic.write_bedgraph(bg, cs, ce, cnt)
+        for pen in pens:
+            db_o = str(tmp_path / "o.db")
+            assert oracle_det.solve(bg, pen, db_o) == 0
+            want.append(open(db_o, "rb").read())
+            problems.append((k, float(pen)))
+            files.append((bg, pen))
+    for knobs in KNOB_COMBINATIONS:
+        for name, value in knobs.items():
+            monkeypatch.setenv(name, value)
+        pset = ProblemSet(contigs, problems)
+        pset.solve()
+        for i, (k, _) in enumerate(problems):
+            r = pset.result(i)
+            assert r.status == 0, (knobs, i, r.kernel_status)
+            if pset.checkpoint_interval > 0:
+                start, mean = pset.segments(i)
+                check_tables_vs_oracle_files(
+                    files[i][0], files[i][1], np.asarray(data[k][2]), np.asarray(data[k][3]), start,
+                    mean, [r.n_segments, r.n_equality_constraints, r.max_intervals,
+                           r.total_intervals, r.best_cost])
+                continue
+            db_g = str(tmp_path / "g.db")
+            pset.export_db(i, np.asarray(data[k][3]).astype(np.int32), db_g)
+            assert open(db_g, "rb").read() == want[i], (knobs, i)
+        print(knobs, pset.kernel_build, pset.solve_stats, pset.park_stats)
+        pset.close()
+        for name in knobs:
+            monkeypatch.delenv(name)
+
