@@ -58,6 +58,9 @@ extern "C" {
  * PEAKSEG_HIP_ARENA_BLOCK_LOG2  tests: log2 of the pieces per arena block (default 19-24)
  * PEAKSEG_HIP_VARIANT=lat|thr|pk  force a build of the forward kernel
  * PEAKSEG_HIP_NO_PACKED=1       the launch planner never picks the packed build (pk)
+ * PEAKSEG_HIP_RATES=lat,thr     diagnostic: data points per second per problem the launch planner
+ *                               assumes for the latency / throughput build (default: measured by
+ *                               this process's earlier solves, else 96000,58000)
  * PEAKSEG_HIP_TIMING=1          phase timings of the file-level calls on stderr */
 
 /* ---- the reference's boundary -------------------------------------------------------- */

@@ -1207,8 +1207,13 @@ struct LiveGrower {
 }  // namespace
 
 /* what the mixed-launch planner assumes a problem advances at, refreshed by every solve that
- * ran on one build alone with every problem resident from the start (a clean measurement) */
-static std::atomic<double> g_lat_rate{90e3}, g_thr_rate{27e3};
+ * ran on one build alone with every problem resident from the start (a clean measurement).
+ * Defaults: an MI355X on contigs of 1e5-1e6 bins -- 96 k data points/s on the latency build;
+ * 63 k on the throughput build with the chip full, 75 k with a CU to itself
+ * (profiles/r04/thr_rate_long_contigs.log; rounds 2-3 assumed 27 k, the round-2 build's rate),
+ * taken a little low: a problem the planner leaves on the throughput build must not end after
+ * the longest one on the latency build. */
+static std::atomic<double> g_lat_rate{96e3}, g_thr_rate{58e3};
 /* a problem on the packed build (a SIMD shared three ways) against one on the throughput build
  * (two ways): 6144 equal problems ran 18.2 % faster six to a CU than four to a CU */
 constexpr double PK_RATE_OF_THR = 1.182 * 4.0 / 6.0;
@@ -1238,8 +1243,8 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
    * the park slots; without them (checkpointed store, very large sets) it is not used */
   if (s->packed && !s->can_park) s->packed = false;
   /* Mixed launch for sets of unequal contigs that oversubscribe the chip: a problem on the
-   * throughput build advances about 27 k data points per second, on the latency build (a CU of
-   * its own) about 90 k, so the longest problems would decide when the set ends.  The L longest
+   * throughput build advances about 60 k data points per second, on the latency build (a CU of
+   * its own) about 96 k, so the longest problems would decide when the set ends.  The L longest
    * problems go to the latency build -- launched first, on a stream of its own, one CU each --
    * and the rest is packed on what is left; L minimises the later of the two predicted ends.
    * (Equal contigs: L = 0.)  The same prediction chooses between the throughput and the packed
@@ -1251,7 +1256,11 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
     /* data points per second of one problem on either build: measured by this process's own
      * earlier solves when there were any (g_lat_rate / g_thr_rate below), else the figures of
      * an MI355X at 2.4 GHz */
-    const double lat_rate = g_lat_rate.load(), thr_rate = g_thr_rate.load();
+    double lat_rate = g_lat_rate.load(), thr_rate = g_thr_rate.load();
+    if (const char *e = getenv("PEAKSEG_HIP_RATES")) { /* diagnostic: "lat,thr" data points per s */
+      double a = 0.0, b = 0.0;
+      if (sscanf(e, "%lf,%lf", &a, &b) == 2 && a > 0.0 && b > 0.0) lat_rate = a, thr_rate = b;
+    }
     std::vector<double> len((size_t)s->n_problems);
     double rest = 0.0;
     for (int k = 0; k < s->n_problems; k++) {
@@ -1284,6 +1293,19 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
     s->packed = s->can_park && !getenv("PEAKSEG_HIP_NO_PACKED") &&
                 !g_pk_handed_over_many.load() && t_pk < 0.97 * t_thr;
     s->n_lat_mixed = s->packed ? l_pk : l_thr;
+    if (getenv("PEAKSEG_HIP_TIMING")) {
+      const int L = s->n_lat_mixed;
+      const double per_cu = s->packed ? 6.0 : 4.0;
+      const double rate = s->packed ? thr_rate * PK_RATE_OF_THR : thr_rate;
+      double on_lat = 0.0;
+      for (int k = 0; k < L; k++) on_lat += len[(size_t)k];
+      fprintf(stderr, "peakseg_hip timing: plan: %d problems, %d on the latency build (predicted end "
+                      "%.2f s), the rest %s (work %.2f s, longest %.2f s); rates %.0f / %.0f per s; "
+                      "all on thr %.2f s, all on pk %.2f s\n", s->n_problems, L,
+              L > 0 ? len[0] / lat_rate : 0.0, s->packed ? "pk" : "thr",
+              (rest - on_lat) / ((double)(s->n_cu - L) * per_cu * rate), len[(size_t)L] / rate,
+              lat_rate, thr_rate, t_thr, t_pk);
+    }
   }
   /* Launches.  The first one runs every problem.  When problems come back unfinished for
    * want of room (arena, spill pool, checkpoint overflow pool) the host enlarges what was short
@@ -1302,6 +1324,7 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
   s->parks = 0;
   s->park_pool_pieces = 0;
   float total_ms = 0.f;
+  hipEvent_t ev_packed_end = nullptr; /* (diagnostic, PEAKSEG_HIP_TIMING) */
   for (int attempt = 0;; attempt++) {
     if (s->ckpt_interval > 0) {
       const unsigned long long B = 1ull << s->d.ar_block_log2;
@@ -1396,6 +1419,9 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
         hipLaunchKernelGGL(psd::thr::fpop_forward_kernel, dim3((unsigned)d_thr.n_problems),
                            dim3(psd::thr::FORWARD_THREADS), 0, s->stream, d_thr);
       HIP_TRY(hipGetLastError());
+      if (getenv("PEAKSEG_HIP_TIMING") && !ev_packed_end && hipEventCreate(&ev_packed_end) != hipSuccess)
+        ev_packed_end = nullptr;
+      if (ev_packed_end) HIP_TRY(hipEventRecord(ev_packed_end, s->stream));
       HIP_TRY(hipEventRecord(s->ev2, s->stream2));
       HIP_TRY(hipStreamWaitEvent(s->stream, s->ev2, 0));
     } else if (thr_now) {
@@ -1429,6 +1455,15 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
     float f_ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&f_ms, s->ev[0], s->ev[1]));
     total_ms += f_ms;
+    if (ev_packed_end) { /* PEAKSEG_HIP_TIMING: when each part of a mixed launch ended */
+      float lat_ms = 0.f, packed_ms = 0.f;
+      if (hipEventElapsedTime(&lat_ms, s->ev[0], s->ev2) == hipSuccess &&
+          hipEventElapsedTime(&packed_ms, s->ev[0], ev_packed_end) == hipSuccess)
+        fprintf(stderr, "peakseg_hip timing: mixed launch: latency part ended at %.2f s, packed part "
+                        "at %.2f s\n", lat_ms / 1e3, packed_ms / 1e3);
+      (void)hipEventDestroy(ev_packed_end);
+      ev_packed_end = nullptr;
+    }
     s->launches++;
     if (forward_ms) *forward_ms = total_ms;
     if (backtrack_ms) *backtrack_ms = 0.f; /* decoding happens inside the forward kernel */
