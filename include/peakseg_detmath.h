@@ -59,6 +59,44 @@ PSD_HD static inline double psd_u2d(uint64_t u) {
   return x;
 }
 
+/* a / b, correctly rounded, for the divisions whose divisor can sit just below a power of two.
+ * On the host that is the division operator.  On the device it is not quite: the quotient of
+ * the compiler's fp64 division sequence (v_div_scale, v_rcp_f64, two Newton steps, v_div_fmas,
+ * v_div_fixup) is one unit off when the exact quotient lies within ~2^-50 of a unit of the
+ * midpoint of two doubles.  That takes a divisor a few units below a power of two (its
+ * significand all ones, the one case the classical proof of this sequence leaves out):
+ * 0x1.6666666666663p-1 / 0x1.ffffffffffffbp-1 gives ...666 instead of ...667; 29 of 8 million
+ * divisions by 1 - k ulp, k < 64, with numerators a few units off small fractions, against 0 of
+ * 8 million with random operands, with divisors 1 + k ulp, or with divisors 2^n -+ k ulp under
+ * numerators up to 60 units off (profiles/r04/div_probe.log).  A divisor of 1 - k ulp is what
+ * the Linear coefficient of a piece that has seen every weight so far is (normalised weights
+ * sum to one less rounding), and -Log / Linear is that piece's optimum: one such quotient made a
+ * prev_log_mean and a breakpoint of a 4851-bin contig differ from the CPU's in their last bits
+ * (found by tools/knob_soak.py, seed 12; tests/golden/division_near_tie.json).
+ * So the quotients by a piece's Linear coefficient are repaired, exactly: the residual
+ * a - q b of the hardware's q (one fma, exact), the neighbour of q on the side the residual
+ * points to, its residual, and the quotient with the smaller one.  (A quotient of two doubles
+ * is never exactly a midpoint: no tie; zero, infinite and NaN quotients fail both comparisons
+ * and stay.)  Twelve instructions -- at every division of the kernel they cost 13 % -- so the
+ * other divisors keep the hardware's sequence: sums of bin widths (a whole number b < 2^48
+ * keeps the quotient 1/(2b) of a unit away from every midpoint), and the iterates and slopes of
+ * the Newton loops and the coefficients of DIFFERENCES of pieces, arbitrary reals that are
+ * within 2^9 units below a power of two once in 2^44 times and then still need the numerator
+ * to match. */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ static inline double psd_div(double a, double b) {
+  const double q = a / b;
+  const double e = psd_fma(-q, b, a);
+  const bool above = (e > 0.0) == (b > 0.0); /* the exact quotient is above q */
+  const uint64_t uq = psd_d2u(q);
+  const double qn = psd_u2d(above == (q > 0.0) ? uq + 1u : uq - 1u);
+  const double en = psd_fma(-qn, b, a);
+  return __builtin_fabs(en) < __builtin_fabs(e) ? qn : q;
+}
+#else
+PSD_HD static inline double psd_div(double a, double b) { return a / b; }
+#endif
+
 /* 2^e for e in [-1022, 1023] */
 PSD_HD static inline double psd_pow2i(int e) {
   return psd_u2d((uint64_t)(e + 1023) << 52);

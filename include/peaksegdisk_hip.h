@@ -279,7 +279,9 @@ int peakseg_hip_paste_double(double x, char *buf, size_t buf_len);
 int peakseg_hip_problem_set_profile(psd_problem_set *set, int problem, long long *out);
 
 /* y[i] = exp(x[i]) (op 0) or log(x[i]) (op 1) evaluated on the device with the library's
- * deterministic math (include/peakseg_detmath.h); tests compare with the host build. */
+ * deterministic math (include/peakseg_detmath.h); op 2: y[i] = psd_div(x[i], x[n + i]) (x holds
+ * n numerators, then n divisors), op 3: the same quotients by the compiler's own fp64 division
+ * sequence, which psd_div repairs; tests compare with the host build. */
 int peakseg_hip_math_probe(int op, int n, const double *x, double *y);
 
 #ifdef __cplusplus

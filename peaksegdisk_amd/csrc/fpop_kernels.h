@@ -13,7 +13,8 @@
  *                         After its last data point the down wave decodes the segmentation
  *                         from the arena (backtrack_wave; drv:399-442: Minimize result, then
  *                         findMean per segment).
- *   math_probe_kernel     element-wise psd_exp / psd_log (tests: host == device bit for bit).
+ *   math_probe_kernel     element-wise psd_exp / psd_log / psd_div (tests: host == device bit
+ *                         for bit) and the compiler's own fp64 division.
  *
  * Included by peakseg_hip.cpp (hipcc, gfx950) and by tests/emu (g++ + hip_emu.h).
  *
@@ -236,6 +237,12 @@ PSD_D bool scale_add_store_wave(const DeviceArgs &a, ArenaCursor &cur, const L &
       f.Lin(i) = li * inv_cum_weight;
       f.Log(i) = lo * inv_cum_weight;
       f.Con(i) = co * inv_cum_weight;
+#ifdef PSD_DEBUG_DUMP /* diagnostic builds: every piece of every function, as bits */
+      printf("D %llu %d %d %016llx %016llx %016llx %016llx %016llx %d\n", fn_index, n, i,
+             (unsigned long long)psd_d2u((double)f.Lin(i)), (unsigned long long)psd_d2u((double)f.Log(i)),
+             (unsigned long long)psd_d2u((double)f.Con(i)), (unsigned long long)psd_d2u(mx),
+             (unsigned long long)psd_d2u(prv), di);
+#endif
       if (store) {
         cursor_mx()[at + i] = mx;
         cursor_prv()[at + i] = prv;
@@ -1319,7 +1326,14 @@ __global__ __launch_bounds__(FORWARD_THREADS) PSD_KERNEL_OCC void fpop_forward_c
 __global__ void math_probe_kernel(int op, int n, const double *x, double *y) {
   psd_tables_init();
   int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (i < n) y[i] = op == 0 ? d_exp(x[i]) : d_log(x[i]);
+  if (i < n) {
+    if (op == 2) /* (x holds n numerators, then n denominators) */
+      y[i] = psd_div(x[i], x[n + i]);
+    else if (op == 3) /* the compiler's division sequence as it is (what psd_div repairs) */
+      y[i] = x[i] / x[n + i];
+    else
+      y[i] = op == 0 ? d_exp(x[i]) : d_log(x[i]);
+  }
 }
 
 }  // namespace PSD_VARIANT

@@ -82,7 +82,8 @@ PSD_D void d_exp2_log(double x0, double x1, double z, double &y0, double &y1, do
 #endif
 
 /* fpl:192-197 */
-PSD_D double argmin_mean(const Coef &c) { return -c.Log / c.Linear; }
+/* (psd_div: Linear is 1 - k ulp for a piece that has seen every weight; peakseg_detmath.h) */
+PSD_D double argmin_mean(const Coef &c) { return psd_div(-c.Log, c.Linear); }
 
 /* fpl:199-204 */
 PSD_D double argmin(const Coef &c) { return d_log(argmin_mean(c)); }

@@ -988,7 +988,7 @@ PSD_D int min_more_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_, 
       PSD_PROF_SUB(PROF_S_LOAD);
       if (tj >= 0) {
         if (c.Log == 0) {
-          sp_mu = mth.log_wild((level - c.Constant) / c.Linear); /* fpl:563 */
+          sp_mu = mth.log_wild(psd_div(level - c.Constant, c.Linear)); /* fpl:563 */
         } else {
           if (has_two_roots(c, o, level)) {
             sp_mu = get_larger_root(c, o, t_mx, t_rc, level, &sp_steps, mth.rare_out());
@@ -1104,7 +1104,7 @@ PSD_D int min_more_impl(L in_, int n_, L out_, int cap_, S s_, int data_i_out_, 
         if (k >= 0) {
           Coef c = load_coef(in, k);
           if (c.Log == 0) {
-            mu = d_log((prev_min_cost - c.Constant) / c.Linear); /* fpl:563 */
+            mu = d_log(psd_div(prev_min_cost - c.Constant, c.Linear)); /* fpl:563 */
           } else {
             PieceOpt o = {s.om(k), s.mu(k), s.muc(k), s.oc2(k)};
             if (has_two_roots(c, o, prev_min_cost)) {

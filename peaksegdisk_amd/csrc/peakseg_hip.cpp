@@ -1325,6 +1325,7 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
   s->park_pool_pieces = 0;
   float total_ms = 0.f;
   hipEvent_t ev_packed_end = nullptr; /* (diagnostic, PEAKSEG_HIP_TIMING) */
+  int arena_rounds = 0;               /* launches of this solve that ran out of arena */
   for (int attempt = 0;; attempt++) {
     if (s->ckpt_interval > 0) {
       const unsigned long long B = 1ull << s->d.ar_block_log2;
@@ -1531,7 +1532,7 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
                 s->resume_t[(size_t)again[k]] ? "(parked)" : "");
       fprintf(stderr, "\n");
     }
-    if (attempt >= 8) {
+    if (attempt >= 12) {
       set_error("cost-function arena (%llu pieces) / spill pool (%d slots) still too small after "
                 "%d relaunches", s->arena_pieces, s->spill_slots, attempt);
       return ERROR_DEVICE_MEMORY;
@@ -1610,7 +1611,11 @@ extern "C" int peakseg_hip_problem_set_solve(psd_problem_set *s, float *forward_
           done += r.status == 0 ? n : (double)r.step_reached;
           if (r.status != 0) rest += n - (double)s->resume_t[(size_t)p];
         }
-        unsigned long long more = s->arena_pieces / 4ull;
+        /* (functions that get longer with t -- adversarial counts -- need more per data point
+         * the further they get: the linear estimate falls short every time, so from the second
+         * exhaustion of a solve on the arena at least doubles) */
+        arena_rounds++;
+        unsigned long long more = arena_rounds >= 2 ? s->arena_pieces : s->arena_pieces / 4ull;
         if (done > 0.0) {
           const double left = (double)(s->d.ar_cap - s->arena_used);
           const double need = (double)s->arena_used / done * rest * 1.3 - left;
@@ -1845,9 +1850,10 @@ extern "C" int peakseg_hip_math_probe(int op, int n, const double *x, double *y)
   }
   if (n <= 0) return 0;
   double *dx = nullptr, *dy = nullptr;
-  HIP_TRY(hipMalloc(&dx, (size_t)n * 8));
+  const size_t n_in = op >= 2 ? (size_t)2 * (size_t)n : (size_t)n; /* (division: two operands) */
+  HIP_TRY(hipMalloc(&dx, n_in * 8));
   HIP_TRY(hipMalloc(&dy, (size_t)n * 8));
-  HIP_TRY(hipMemcpy(dx, x, (size_t)n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dx, x, n_in * 8, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(psd::lat::math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t) nullptr, op, n, dx, dy);
   HIP_TRY(hipGetLastError());

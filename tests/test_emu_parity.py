@@ -286,3 +286,8 @@ def test_emu_knob_combinations_on_a_mixed_set(psd, oracle_det, tmp_path, monkeyp
     gp4.test_knob_combinations_on_a_mixed_set(psd, oracle_det, tmp_path, monkeypatch,
                                               n_poisson=600, n_increasing=500, n_shapes=2)
 
+
+def test_emu_division_near_a_midpoint(psd, oracle_det, tmp_path, monkeypatch):
+    # (the host divides exactly: this pins the data set and the oracle's stores, not psd_div)
+    gp4.test_division_near_a_midpoint(psd, oracle_det, tmp_path, monkeypatch)
+

@@ -14,6 +14,7 @@ import ctypes
 import os
 import shutil
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -416,4 +417,63 @@ def test_knob_combinations_on_a_mixed_set(psd, oracle_det, tmp_path, monkeypatch
         pset.close()
         for name in knobs:
             monkeypatch.delenv(name)
+
+
+def _near_tie_problem():
+    import json
+    g = json.load(open(os.path.join(GOLDEN, "division_near_tie.json")))
+    return (np.array(g["chromStart"], dtype=np.int32), np.array(g["chromEnd"], dtype=np.int32),
+            np.array(g["count"], dtype=np.int32), g["penalties"], g["db_sha256"])
+
+
+@GPU
+def test_division_near_a_midpoint(psd, oracle_det, tmp_path, monkeypatch):
+    """The MI355X's fp64 division sequence is one unit off when the exact quotient lies within
+    ~2^-50 of a unit of a midpoint between two doubles, which divisors of 1 - k ulp produce --
+    and the Linear coefficient of a piece that has seen every weight is such a number.  The
+    64-bin problem of tests/golden/division_near_tie.json has that quotient at data point 47
+    (0x1.6666666666663p-1 / 0x1.ffffffffffffbp-1): before psd_div (include/peakseg_detmath.h) its
+    stores differed from the oracle's in a prev_log_mean and a breakpoint, on every build."""
+    from peaksegdisk_amd import ProblemSet, synthetic
+    import hashlib
+    cs, ce, cnt, pens, sha = _near_tie_problem()
+    bg = str(tmp_path / "c.bedGraph")
+    synthetic.write_bedgraph(bg, cs, ce, cnt)
+    want = []
+    for pen in pens:
+        db_o = str(tmp_path / "o.db")
+        assert oracle_det.solve(bg, pen, db_o) == 0
+        want.append(open(db_o, "rb").read())
+        assert hashlib.sha256(want[-1]).hexdigest() == sha["det:" + pen]
+    for build in ("lat", "thr", "pk"):
+        monkeypatch.setenv("PEAKSEG_HIP_VARIANT", build)
+        pset = ProblemSet([(cnt, (ce - cs).astype(np.int32))], [(0, float(p)) for p in pens])
+        pset.solve()
+        for i, pen in enumerate(pens):
+            assert pset.result(i).status == 0
+            db_g = str(tmp_path / "g.db")
+            pset.export_db(i, ce, db_g)
+            assert open(db_g, "rb").read() == want[i], (build, pen)
+        pset.close()
+    monkeypatch.delenv("PEAKSEG_HIP_VARIANT")
+
+
+@GPU
+def test_psd_div_is_ieee_division(psd):
+    """psd_div on the device == the host's division, bit for bit, on random operands and on the
+    structured ones that come closest to midpoints (divisors a few units either side of powers
+    of two under numerators a few units off small fractions: tools/div_probe.py, where the
+    compiler's own sequence is 29 of 8 million off)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import div_probe
+    from peaksegdisk_amd import _native
+    raw_off = 0
+    for name, a, b in div_probe.cases(n=2000000, seed=17):
+        want = a / b
+        got = div_probe.device_div(2, a, b)
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), name
+        raw = div_probe.device_div(3, a, b)
+        raw_off += int(np.count_nonzero(raw.view(np.uint64) != want.view(np.uint64)))
+    print("quotients the compiler's own sequence has one unit off: %d" % raw_off)
+    assert raw_off > 0, "the hardware's division agrees with IEEE on the known near-midpoint quotient?"
 

@@ -9,6 +9,7 @@ import hashlib
 import os
 import shutil
 
+import numpy as np
 import pytest
 
 from conftest import GOLDEN, read_loss, read_segments
@@ -144,3 +145,24 @@ def test_mono27ac(pen, oracle_libm, oracle_det, known_answers, tmp_path):
             assert float(loss[6]) == pytest.approx(float(want["total_loss"]), rel=REL_TOL)
     # endpoints, states and 6-digit means identical between the two math builds
     assert results["libm"][0] == results["det"][0]
+
+
+def test_division_near_tie_fixture(oracle_libm, oracle_det, tmp_path):
+    """tests/golden/division_near_tie.json: 64 bins whose data point 47 divides
+    0x1.6666666666663p-1 by 0x1.ffffffffffffbp-1 (the quotient 6e-17 of a unit from a midpoint,
+    which the MI355X's division sequence gets one unit off, include/peakseg_detmath.h): the
+    stores both oracle builds write are pinned by their hashes, and the host's division gives
+    the IEEE quotient."""
+    import json
+    from peaksegdisk_amd import synthetic
+    g = json.load(open(os.path.join(GOLDEN, "division_near_tie.json")))
+    assert (float.fromhex("0x1.6666666666663p-1") / float.fromhex("0x1.ffffffffffffbp-1")).hex() \
+        == "0x1.6666666666667p-1"
+    bg = str(tmp_path / "c.bedGraph")
+    synthetic.write_bedgraph(bg, np.array(g["chromStart"]), np.array(g["chromEnd"]), np.array(g["count"]))
+    for name, oracle in (("det", oracle_det), ("libm", oracle_libm)):
+        for pen in g["penalties"]:
+            db = str(tmp_path / "o.db")
+            assert oracle.solve(bg, pen, db) == 0
+            assert hashlib.sha256(open(db, "rb").read()).hexdigest() == g["db_sha256"]["%s:%s" % (name, pen)]
+
