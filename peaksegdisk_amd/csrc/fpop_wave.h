@@ -1244,7 +1244,7 @@ PSD_D void env_interval(const Coef &c1, const Coef &c2, double a, double b, bool
       cand_one(out, d.Linear < 0 ? 0 : 1, a, b);
       return;
     }
-    double x = d_log(-d.Constant / d.Linear);
+    double x = d_log(psd_div(-d.Constant, d.Linear));
     if (a < x && x < b) {
       int first = (0 < d.Linear) ? 0 : 1;
       cand_two(out, first, x);
@@ -1498,7 +1498,9 @@ PSD_D void env_classify_lanes(bool valid, const Coef &c1, const Coef &c2, double
    * interval, evaluated in three interleaved pairs (the values are those of the single calls):
    * exp(a) | exp(b), log(midpoint) | log(argmin_mean), exp for the cost at each of the two. */
   double ea = 0.0, eb = 0.0, cost_diff_mid = 0.0;
-  const double larg = degen ? (-d.Constant / d.Linear) : (-d.Log / d.Linear);
+  /* (psd_div: against a constant piece the difference has the function piece's own Linear,
+   * which may be 1 - k ulp; peakseg_detmath.h) */
+  const double larg = degen ? psd_div(-d.Constant, d.Linear) : psd_div(-d.Log, d.Linear);
   const bool need_l = degen_root || rootp;
   double lres = 0.0;
   PieceOpt o = {0.0, 0.0, 0.0, 0.0};
@@ -1761,7 +1763,7 @@ PSD_D int helper_root_lanes(Mail &m, int lane) {
     const Coef d = {m.d_lin[lane], m.d_log[lane], m.d_con[lane]};
     /* the optimum of the difference piece exactly as env_classify_lanes derives it */
     PieceOpt o;
-    o.mean = -d.Log / d.Linear;
+    o.mean = psd_div(-d.Log, d.Linear); /* (as env_classify_lanes: the same quotient) */
     o.log_mean = mth.log(o.mean);
     o.cost = mth.cost(d, o.log_mean);
     double loss_without_log_term = d.Linear * o.mean + d.Constant;
