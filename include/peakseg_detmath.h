@@ -73,7 +73,9 @@ PSD_HD static inline double psd_u2d(uint64_t u) {
  * sum to one less rounding), and -Log / Linear is that piece's optimum: one such quotient made a
  * prev_log_mean and a breakpoint of a 4851-bin contig differ from the CPU's in their last bits
  * (found by tools/knob_soak.py, seed 12; tests/golden/division_near_tie.json).
- * So the quotients by a piece's Linear coefficient are repaired, exactly: the residual
+ * So the quotients by a piece's Linear coefficient (the optimum of a piece, the degenerate
+ * crossing, and the envelope's difference pieces, whose Linear is the function piece's own
+ * against a constant piece) are repaired, exactly: the residual
  * a - q b of the hardware's q (one fma, exact), the neighbour of q on the side the residual
  * points to, its residual, and the quotient with the smaller one.  (A quotient of two doubles
  * is never exactly a midpoint: no tie; zero, infinite and NaN quotients fail both comparisons
