@@ -85,16 +85,18 @@ PSD_HD static inline double psd_u2d(uint64_t u) {
  * the Newton loops and the coefficients of DIFFERENCES of pieces, arbitrary reals that are
  * within 2^9 units below a power of two once in 2^44 times and then still need the numerator
  * to match. */
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ static inline double psd_div(double a, double b) {
-  const double q = a / b;
+/* q: a quotient of a by b that is at most one unit off; returns the correctly rounded one
+ * (host and device: tests/test_oracle_golden.py feeds it the IEEE quotient's neighbours) */
+PSD_HD static inline double psd_div_repair(double q, double a, double b) {
   const double e = psd_fma(-q, b, a);
-  const bool above = (e > 0.0) == (b > 0.0); /* the exact quotient is above q */
+  const int above = (e > 0.0) == (b > 0.0); /* the exact quotient is above q */
   const uint64_t uq = psd_d2u(q);
   const double qn = psd_u2d(above == (q > 0.0) ? uq + 1u : uq - 1u);
   const double en = psd_fma(-qn, b, a);
   return __builtin_fabs(en) < __builtin_fabs(e) ? qn : q;
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ static inline double psd_div(double a, double b) { return psd_div_repair(a / b, a, b); }
 #else
 PSD_HD static inline double psd_div(double a, double b) { return a / b; }
 #endif

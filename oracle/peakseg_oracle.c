@@ -42,6 +42,14 @@ void oracle_exp_vec(int n, const double *x, double *y) {
 void oracle_log_vec(int n, const double *x, double *y) {
   for (int i = 0; i < n; i++) y[i] = O_LOG(x[i]);
 }
+#ifdef PEAKSEG_DETMATH_H
+/* x: n quotients, then n numerators, then n divisors; y[i] = psd_div_repair(q, a, b): the repair
+ * the device applies to its own division (include/peakseg_detmath.h), run on the host so that a
+ * test can hand it quotients that are one unit off */
+void oracle_div_repair_vec(int n, const double *x, double *y) {
+  for (int i = 0; i < n; i++) y[i] = psd_div_repair(x[i], x[n + i], x[2 * n + i]);
+}
+#endif
 
 /* ref: funPieceListLog.h:11-34 */
 typedef struct {

@@ -166,3 +166,40 @@ def test_division_near_tie_fixture(oracle_libm, oracle_det, tmp_path):
             assert oracle.solve(bg, pen, db) == 0
             assert hashlib.sha256(open(db, "rb").read()).hexdigest() == g["db_sha256"]["%s:%s" % (name, pen)]
 
+
+def test_division_repair_restores_the_ieee_quotient(oracle_det):
+    """psd_div_repair (include/peakseg_detmath.h), what the device applies to the quotient of its
+    own division sequence, run on the host: handed the IEEE quotient or either of its
+    neighbours -- for random operands of both signs and many magnitudes, and for the operands
+    that come closest to midpoints -- it returns the IEEE quotient; zero, infinite and NaN
+    quotients pass through."""
+    import ctypes
+    rng = np.random.default_rng(11)
+    n = 400000
+    a = rng.uniform(0.5, 2, n) * 2.0 ** rng.integers(-300, 300, n) * rng.choice([-1.0, 1.0], n)
+    b = rng.uniform(0.5, 2, n) * 2.0 ** rng.integers(-300, 300, n) * rng.choice([-1.0, 1.0], n)
+
+    def pert(v, k):
+        return (np.ascontiguousarray(v).view(np.int64) + k).view(np.float64)
+    frac = pert(rng.integers(1, 200, n) / rng.integers(1, 200, n), rng.integers(-8, 9, n))
+    near = pert(np.ones(n), -rng.integers(0, 64, n))
+    a = np.concatenate([a, frac, [float.fromhex("0x1.6666666666663p-1")]])
+    b = np.concatenate([b, near, [float.fromhex("0x1.ffffffffffffbp-1")]])
+    want = a / b
+
+    def repair(q):
+        x = np.ascontiguousarray(np.concatenate([q, a, b]))
+        y = np.empty(a.size)
+        oracle_det.lib.oracle_div_repair_vec(ctypes.c_int(a.size), x.ctypes.data_as(ctypes.c_void_p),
+                                             y.ctypes.data_as(ctypes.c_void_p))
+        return y
+    for q in (want, np.nextafter(want, np.inf), np.nextafter(want, -np.inf)):
+        assert np.array_equal(repair(q).view(np.uint64), want.view(np.uint64))
+    # special quotients stay as they are
+    a = np.array([0.0, -0.0, 1.0, -1.0, np.nan, np.inf])
+    b = np.array([3.0, 3.0, 0.0, 0.0, 2.0, 2.0])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        want = a / b
+    got = repair(want)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
