@@ -883,10 +883,20 @@ extern "C" int peakseg_hip_problem_set_create(int device, int n_contigs, const i
     count.insert(count.end(), contig_count[c], contig_count[c] + n);
     weight.insert(weight.end(), contig_weight[c], contig_weight[c] + n);
     double mn = INFINITY, mx = -INFINITY;
+    long long width_sum = 0;
     for (int i = 0; i < n; i++) { /* drv:198-204 */
       double log_data = psd_log((double)contig_count[c][i]);
       if (log_data < mn) mn = log_data;
       if (mx < log_data) mx = log_data;
+      width_sum += contig_weight[c][i];
+    }
+    /* (the kernels divide by cumulated widths with the hardware's division, which is the IEEE
+     * quotient for whole-number divisors below 2^48, peakseg_detmath.h; chromosome coordinates
+     * are 32-bit, so this never triggers on a bedGraph file) */
+    if (width_sum >= (1ll << 48)) {
+      set_error("contig %d: the bin widths sum to 2^48 or more", c);
+      peakseg_hip_problem_set_destroy(s);
+      return ERROR_DEVICE_SOLVER;
     }
     min_lm[c] = mn;
     max_lm[c] = mx;
